@@ -1,0 +1,175 @@
+/*
+ * prograph_hip.h — C ABI of the MI355X (gfx950) graph-construction hot path.
+ *
+ * The reference (acmater/prograph) has no FFI: its plug-in contract is the Python
+ * distance-function protocol `distance(X (N,D), Y (M,D), similarity=False) -> (M,N)`
+ * (prograph/distance/hamming.py:8-39, README.md:48) plus the stock torch ops that
+ * `Prograph.build_graph` (prograph/prograph.py:656-765) and `Prograph.indexing`
+ * (prograph/prograph.py:254-343) run on `cuda:0`.  Each entry point below names the
+ * reference call site(s) it replaces; INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors are the
+ *     storage container); the library never allocates, frees or synchronises;
+ *   - every launch goes to the caller-supplied `stream` (a hipStream_t passed as void*,
+ *     NULL = the null stream); calls are re-entrant per stream;
+ *   - return value: 0 = ok, >0 = a hipError_t from the launch, <0 = PG_E_* below;
+ *     `pg_last_error()` returns a thread-local human readable message;
+ *   - no exceptions cross the boundary, no hidden global state.
+ *
+ * Token storage: the "plane" layout.  A token matrix of N sequences x L byte tokens
+ * is held as Q = ceil(L/16) planes of Npad 16-byte chunks, chunk q of sequence n at
+ * byte offset (q*Npad + n)*16; bytes past L inside a sequence and sequences past N
+ * are zero.  Npad = pg_npad(N) (a multiple of 256).  A 64-lane wavefront that owns 64
+ * consecutive sequences therefore reads one plane chunk per lane as a single fully
+ * coalesced 1 KiB `global_load_dwordx4`.
+ */
+#ifndef PROGRAPH_HIP_H
+#define PROGRAPH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+
+/* library error codes (negative return values) */
+#define PG_E_BADARG   (-1)   /* NULL pointer, negative size, k out of range ...        */
+#define PG_E_TOOLONG  (-2)   /* L > PG_MAX_L for this entry point                       */
+#define PG_E_TOOMANY  (-3)   /* N > PG_MAX_N_KNN (24-bit column index in packed keys)   */
+#define PG_E_NODEV    (-4)   /* no HIP device / wrong architecture                      */
+
+#define PG_MAX_L      128          /* bytes per sequence the single-pass kernels take   */
+#define PG_MAX_N_KNN  16777216     /* 2^24                                               */
+#define PG_MAX_K      63           /* k+1 sorted keys live in the 64 lanes of one VGPR   */
+
+/* token alphabets: selects the nonzero-byte test of the mismatch counter */
+#define PG_ALPHA_5BIT 5            /* every token <= 31   (7 VALU ops / 12 tokens)       */
+#define PG_ALPHA_7BIT 7            /* every token <= 127  (3 VALU ops / 4 tokens)        */
+#define PG_ALPHA_8BIT 8            /* any byte            (5 VALU ops / 4 tokens)        */
+
+/* comparator codes for pg_eps_*: the reference's `comp` argument (operator.le default,
+ * prograph/prograph.py:665) restricted to the five orderings                      */
+#define PG_CMP_LE 0
+#define PG_CMP_LT 1
+#define PG_CMP_EQ 2
+#define PG_CMP_GE 3
+#define PG_CMP_GT 4
+
+int         pg_version(void);
+const char *pg_last_error(void);
+int         pg_device_info(int *cu_count, int *wave_size, char *arch, int arch_len);
+
+/* Npad for N sequences (multiple of 256), Q for L bytes (ceil(L/16)). */
+int64_t     pg_npad(int64_t n);
+int         pg_nplanes(int l);
+
+/*
+ * pg_pack_planes — row-major tokens -> plane layout.
+ * Replaces the H->D staging `torch.as_tensor(self(representation), dtype=float16,
+ * device="cuda:0")[idxs,:]` (prograph/prograph.py:726) and the zero right-padding of
+ * `clean_input` (prograph/distance/utils.py:32-38).
+ *   src        (n, l) row-major, leading dimension `ld` ELEMENTS, element size
+ *              `elem_bytes` in {1,2,4,8} (uint8 / int16 / int32 / int64 tokens)
+ *   rows       optional int64[n] gather list (the reference's `idxs`), NULL = identity
+ *   planes     out, Q*npad*16 bytes, fully overwritten (padding zeroed)
+ *   flags      out, uint32[1], OR-ed: bit0 = some token > 127, bit1 = some token
+ *              outside 0..255 (such tokens are truncated; caller must not use result)
+ */
+int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld,
+                   const int64_t *rows, void *planes, int64_t npad, uint32_t *flags,
+                   void *stream);
+
+/*
+ * pg_hamming_dense — all-pairs Hamming distance matrix.
+ * Replaces `torch.sum(X != Y[:,None,:], axis=2)` (prograph/distance/hamming.py:34;
+ * K2+K3 of SURVEY.md §2.2).  out[m*ldo + n] = #{j : Y[m,j] != X[n,j]}, (M,N) like the
+ * reference.  out_elem_bytes in {1,4,8} (uint8 / int32 / int64 = the reference's dtype).
+ */
+int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad,
+                     const void *y_planes, int64_t m, int64_t y_npad,
+                     int l, int alpha, void *out, int out_elem_bytes, int64_t ldo,
+                     void *stream);
+
+/*
+ * pg_eps_slots — the N^2 pass of the epsilon-neighbourhood graph.
+ * Replaces the hot loop `distance(X,batch)` -> `comp(d,eps) & (d>0)` -> `torch.where`
+ * -> gather of `build_graph` (prograph/prograph.py:731-739; K2..K7) for rows
+ * [row0, row0+nrows) of `row_planes` against all `ncols` sequences of `col_planes`.
+ * For every row the matching column indices are written in ascending order into the
+ * row's slot (capacity `cap`), and the exact number of matches into counts[] even when
+ * it exceeds `cap` (pg_eps_compact recomputes such rows).
+ *   cmp, eps   PG_CMP_* and the threshold; pairs with d == 0 are always excluded
+ *   slot_idx   int32 [nrows*cap], slot_w uint8 [nrows*cap], counts uint32 [nrows]
+ */
+int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
+                 const void *col_planes, int64_t col_npad, int64_t ncols,
+                 int l, int alpha, int cmp, double eps, int cap,
+                 int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts, void *stream);
+
+/*
+ * pg_exclusive_scan — indptr[0..n] = exclusive prefix sum of counts[0..n) (int64).
+ * Replaces the per-row split of `prod_neighbours` (prograph/prograph.py:646-654).
+ * `scratch` must hold pg_scan_scratch_bytes(n) bytes.
+ */
+int64_t pg_scan_scratch_bytes(int64_t n);
+int pg_exclusive_scan(const uint32_t *counts, int64_t n, int64_t *indptr, void *scratch,
+                      void *stream);
+
+/*
+ * pg_eps_compact — slots -> CSR.  indices/weights must hold indptr[nrows] entries.
+ * Rows whose count exceeded `cap` are recomputed in place (same arguments as
+ * pg_eps_slots).  Output: indices int32 ascending per row (the order `torch.where`
+ * yields, prograph/prograph.py:736), weights uint8 = the Hamming distance.
+ */
+int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
+                   const void *col_planes, int64_t col_npad, int64_t ncols,
+                   int l, int alpha, int cmp, double eps, int cap,
+                   const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts,
+                   const int64_t *indptr, int32_t *indices, uint8_t *weights, void *stream);
+
+/*
+ * pg_knn_hamming — k nearest neighbours under the canonical (distance, index) order.
+ * Replaces `torch.sort(distance(X,batch),dim=1)` + `[:,1:k+1]` (prograph/prograph.py:
+ * 758-762; K8,K9): for each row the k+1 smallest (d, column) pairs are kept, rank 0 is
+ * dropped (not "self": prograph/prograph.py:761-763), ranks 1..k are written.
+ * Ranks that do not exist (ncols < k+1) get idx = -1, dist = 255.
+ *   idx_out int32 [nrows*k], dist_out uint8 [nrows*k];  1 <= k <= PG_MAX_K
+ */
+int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
+                   const void *col_planes, int64_t col_npad, int64_t ncols,
+                   int l, int alpha, int k, int32_t *idx_out, uint8_t *dist_out,
+                   void *stream);
+
+/*
+ * pg_index_flags — the fused 1xN pass of `Prograph.indexing` (prograph/prograph.py:
+ * 298-325): distance of every sequence to reference row `ref`, a 256-bin histogram of
+ * those distances (for the `d in np.unique(d_data)` assertion, :305), and
+ * flags[n] = dist_ok(n) && pos_ok(n) where
+ *   dist_ok = want_dist == NULL || bit d of the 256-bit set want_dist[8] is set
+ *   pos_ok  = pos_mode == 0, or: (pos_mode 1 "or": some byte selected by pos_mask
+ *             differs from the reference row; 2 "and": all selected bytes differ) and no
+ *             byte selected by not_mask differs          (:316-325)
+ * pos_mask / not_mask: uint8[Q*16] (0xFF = selected) device arrays.
+ *   dist_out uint8[n] (may be NULL), hist uint64[256] (may be NULL; must be zeroed by
+ *   the caller), flags uint8[n] (may be NULL)
+ */
+int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int alpha,
+                   int64_t ref, const uint32_t *want_dist, int pos_mode,
+                   const uint8_t *pos_mask, const uint8_t *not_mask,
+                   uint8_t *dist_out, uint64_t *hist, uint8_t *flags, void *stream);
+
+/*
+ * pg_compact_flags — ascending indices of the non-zero flags (np.where(...)[0]).
+ *   out_idx int64[n] (worst case), out_count int64[1]; scratch: pg_scan_scratch_bytes(n)
+ */
+int pg_compact_flags(const uint8_t *flags, int64_t n, int64_t *out_idx, int64_t *out_count,
+                     void *scratch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROGRAPH_HIP_H */

@@ -1,0 +1,305 @@
+"""
+ctypes binding of libprograph_hip.so (include/prograph_hip.h) — the only way the package
+reaches the GPU for the hot path.  torch tensors are used as device storage and for the
+stream handle only.
+
+There is NO CPU or eager fallback for the native entry points: if the shared library is
+missing, was built for another ABI, or no HIP device is visible, every call raises
+`NativeUnavailable` (a RuntimeError) with the reason.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+import torch   # must be imported before the library is loaded: see _load()
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprograph_hip.so")
+ABI_VERSION = 1
+
+ALPHA_5BIT, ALPHA_7BIT, ALPHA_8BIT = 5, 7, 8
+CMP_LE, CMP_LT, CMP_EQ, CMP_GE, CMP_GT = 0, 1, 2, 3, 4
+MAX_L, MAX_K, MAX_N_KNN = 128, 63, 1 << 24
+
+# every symbol include/prograph_hip.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_nplanes", "pg_pack_planes",
+    "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
+    "pg_eps_compact", "pg_knn_hamming", "pg_index_flags", "pg_compact_flags",
+]
+
+
+class NativeUnavailable(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+_i64, _i32, _vp, _dbl = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
+
+
+def _load():
+    """dlopen the library AFTER torch: hipcc stamps NEEDED libamdhip64.so.7 into it and torch
+    ships a runtime with the same SONAME, so the loader binds us to the HIP runtime torch has
+    already mapped.  One runtime per process is what makes torch-allocated pointers valid in
+    our launches (SURVEY.md §7 hard part 1)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeUnavailable(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C prograph_amd/csrc` (hipcc, --offload-arch=gfx950)")
+        try:
+            lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        except OSError as e:
+            raise NativeUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+        missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+        if missing:
+            raise NativeUnavailable(f"{LIB_PATH} does not export {missing}")
+        lib.pg_version.restype = _i32
+        if lib.pg_version() != ABI_VERSION:
+            raise NativeUnavailable(f"ABI mismatch: library {lib.pg_version()}, binding {ABI_VERSION}")
+        lib.pg_last_error.restype = ctypes.c_char_p
+        lib.pg_npad.restype = _i64
+        lib.pg_npad.argtypes = [_i64]
+        lib.pg_nplanes.restype = _i32
+        lib.pg_nplanes.argtypes = [_i32]
+        lib.pg_scan_scratch_bytes.restype = _i64
+        lib.pg_scan_scratch_bytes.argtypes = [_i64]
+        lib.pg_device_info.argtypes = [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32]
+        lib.pg_pack_planes.argtypes = [_vp, _i32, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp]
+        lib.pg_hamming_dense.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i64, _vp]
+        lib.pg_eps_slots.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
+                                     _vp, _vp, _vp, _vp]
+        lib.pg_exclusive_scan.argtypes = [_vp, _i64, _vp, _vp, _vp]
+        lib.pg_eps_compact.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        lib.pg_knn_hamming.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
+        lib.pg_index_flags.argtypes = [_vp, _i64, _i64, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
+        lib.pg_compact_flags.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
+        for name in SYMBOLS:
+            fn = getattr(lib, name)
+            if fn.restype is ctypes.c_int and name not in ("pg_version",):
+                fn.restype = _i32
+        _lib = lib
+        return lib
+
+
+def lib():
+    return _load()
+
+
+def device():
+    """The device the hot path runs on: the current CUDA(HIP) device of this process."""
+    if not torch.cuda.is_available():
+        raise NativeUnavailable("no HIP device visible to torch; the Hamming/graph path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().pg_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def npad(n):
+    return ((max(int(n), 1) + 255) // 256) * 256
+
+
+def nplanes(l):
+    return (max(int(l), 1) + 15) // 16
+
+
+class Planes:
+    """Device-resident token matrix in plane layout (see include/prograph_hip.h)."""
+    __slots__ = ("buf", "n", "l", "npad", "q", "alpha", "max_flags")
+
+    def __init__(self, buf, n, l, alpha, max_flags):
+        self.buf, self.n, self.l = buf, int(n), int(l)
+        self.npad, self.q, self.alpha, self.max_flags = npad(n), nplanes(l), alpha, max_flags
+
+    @property
+    def nbytes(self):
+        return self.buf.numel()
+
+
+def pack(tokens, rows=None, alpha=None):
+    """
+    (N, L) integer tokens (torch tensor on the GPU, or anything np.asarray takes) -> Planes.
+    `rows`: optional index list (the reference's `idxs`, prograph/prograph.py:726).
+    Raises ValueError when a token does not fit a byte: such data is not "tokenized" and the
+    caller must take the generic torch path.
+    """
+    L = lib()
+    dev = device()
+    if not isinstance(tokens, torch.Tensor):
+        tokens = torch.from_numpy(np.ascontiguousarray(np.asarray(tokens)))
+    if tokens.dim() != 2:
+        raise ValueError("token matrix must be 2-D")
+    if tokens.dtype not in (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64):
+        raise TypeError(f"integer tokens expected, got {tokens.dtype}")
+    if tokens.dtype == torch.int8:
+        tokens = tokens.view(torch.uint8) if bool((tokens >= 0).all()) else tokens.to(torch.int16)
+    tokens = tokens.to(dev).contiguous()
+    n_src, l = tokens.shape
+    if l > MAX_L:
+        raise ValueError(f"L={l} exceeds the native limit of {MAX_L}")
+    ridx = None
+    n = n_src
+    if rows is not None:
+        ridx = torch.as_tensor(np.asarray(rows), dtype=torch.int64).reshape(-1)
+        if ridx.numel() and (int(ridx.min()) < -n_src or int(ridx.max()) >= n_src):
+            raise IndexError("row index out of range")
+        ridx = torch.where(ridx < 0, ridx + n_src, ridx).to(dev)
+        n = int(ridx.numel())
+    if n == 0:
+        raise ValueError("empty token matrix")
+    np_, q = npad(n), nplanes(l)
+    buf = torch.empty(q * np_ * 16, dtype=torch.uint8, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    _check(L.pg_pack_planes(_ptr(tokens), tokens.element_size(), n, l, tokens.stride(0), _ptr(ridx), _ptr(buf), np_,
+                            _ptr(flags), _stream()), "pg_pack_planes")
+    f = int(flags.item())
+    if f & 2:
+        raise ValueError("tokens outside 0..255 cannot use the byte-token Hamming path")
+    if alpha is None:
+        if f & 1:
+            alpha = ALPHA_8BIT
+        else:
+            alpha = ALPHA_7BIT
+    return Planes(buf, n, l, alpha, f)
+
+
+def refine_alpha(planes, max_token):
+    """Callers that know the alphabet size (Prograph: len(amino_acids)) pick the 5-bit counter."""
+    if max_token <= 31 and planes.alpha == ALPHA_7BIT:
+        planes.alpha = ALPHA_5BIT
+    return planes
+
+
+_TORCH_OUT = {1: torch.uint8, 4: torch.int32, 8: torch.int64}
+
+
+def hamming_dense(xp, yp, out_bytes=8):
+    """(M, N) distance matrix of every row of `yp` against every row of `xp` (hamming.py:34)."""
+    if xp.q != yp.q:
+        raise ValueError("operands must be packed with the same padded length")
+    out = torch.empty((yp.n, xp.n), dtype=_TORCH_OUT[out_bytes], device=xp.buf.device)
+    alpha = max(xp.alpha, yp.alpha)
+    _check(lib().pg_hamming_dense(_ptr(xp.buf), xp.n, xp.npad, _ptr(yp.buf), yp.n, yp.npad, xp.q * 16, alpha,
+                                  _ptr(out), out_bytes, out.stride(0), _stream()), "pg_hamming_dense")
+    return out
+
+
+def _alpha2(rp, cp):
+    return max(rp.alpha, cp.alpha)
+
+
+def eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
+    """
+    Epsilon-neighbourhood CSR of rows [row0, row0+nrows) of `rp` against all of `cp`.
+    Returns device tensors (indptr int64 [nrows+1], indices int32 [nnz], weights uint8 [nnz]).
+    One host sync (reading nnz) sits between the N^2 pass and the compaction.
+    """
+    L = lib()
+    nrows = rp.n - row0 if nrows is None else int(nrows)
+    dev = rp.buf.device
+    alpha = _alpha2(rp, cp)
+    cap = int(cap)
+    slot_idx = torch.empty(nrows * cap, dtype=torch.int32, device=dev)
+    slot_w = torch.empty(nrows * cap, dtype=torch.uint8, device=dev)
+    counts = torch.empty(nrows, dtype=torch.int32, device=dev)
+    indptr = torch.empty(nrows + 1, dtype=torch.int64, device=dev)
+    scratch = torch.empty(int(L.pg_scan_scratch_bytes(nrows)), dtype=torch.uint8, device=dev)
+    args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.q * 16, alpha, cmp, float(eps), cap)
+    _check(L.pg_eps_slots(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _stream()), "pg_eps_slots")
+    _check(L.pg_exclusive_scan(_ptr(counts), nrows, _ptr(indptr), _ptr(scratch), _stream()), "pg_exclusive_scan")
+    nnz = int(indptr[-1].item())
+    indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+    weights = torch.empty(max(nnz, 1), dtype=torch.uint8, device=dev)[:nnz]
+    if nnz:
+        _check(L.pg_eps_compact(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _ptr(indptr), _ptr(indices),
+                                _ptr(weights), _stream()), "pg_eps_compact")
+    return indptr, indices, weights
+
+
+def eps_slots_only(rp, cp, cmp, eps, row0, nrows, cap, slot_idx, slot_w, counts):
+    """Just the N^2 launch on preallocated buffers (bench.py times this)."""
+    args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.q * 16, _alpha2(rp, cp), cmp,
+            float(eps), int(cap))
+    _check(lib().pg_eps_slots(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _stream()), "pg_eps_slots")
+
+
+def knn_graph(rp, cp, k, row0=0, nrows=None, out=None):
+    """(nrows, k) int32 indices and uint8 distances, ranks 1..k of the canonical order."""
+    nrows = rp.n - row0 if nrows is None else int(nrows)
+    dev = rp.buf.device
+    if out is None:
+        idx = torch.empty((nrows, k), dtype=torch.int32, device=dev)
+        dist = torch.empty((nrows, k), dtype=torch.uint8, device=dev)
+    else:
+        idx, dist = out
+    _check(lib().pg_knn_hamming(_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.q * 16,
+                                _alpha2(rp, cp), int(k), _ptr(idx), _ptr(dist), _stream()), "pg_knn_hamming")
+    return idx, dist
+
+
+def index_flags(planes, ref, want=None, pos_mode=0, pos_mask=None, not_mask=None, want_dist_out=True,
+                want_hist=True, want_flags=True):
+    """Fused 1xN pass of Prograph.indexing; returns (dist uint8[n] | None, hist int64[256] | None, flags | None)."""
+    dev = planes.buf.device
+    n = planes.n
+    dist = torch.empty(n, dtype=torch.uint8, device=dev) if want_dist_out else None
+    hist = torch.zeros(256, dtype=torch.int64, device=dev) if want_hist else None
+    flags = torch.empty(n, dtype=torch.uint8, device=dev) if want_flags else None
+    wt = None
+    if want is not None:
+        bits = np.zeros(8, dtype=np.uint32)
+        for d in want:
+            d = int(d)
+            if 0 <= d < 256:
+                bits[d >> 5] |= np.uint32(1 << (d & 31))
+        wt = torch.from_numpy(bits.view(np.int32)).to(dev)
+    pm = nm = None
+    if pos_mode:
+        pm = torch.from_numpy(np.ascontiguousarray(pos_mask, dtype=np.uint8)).to(dev)
+        nm = torch.from_numpy(np.ascontiguousarray(not_mask, dtype=np.uint8)).to(dev)
+        assert pm.numel() == planes.q * 16 and nm.numel() == planes.q * 16
+    alpha = ALPHA_8BIT if planes.alpha == ALPHA_8BIT else ALPHA_7BIT
+    _check(lib().pg_index_flags(_ptr(planes.buf), n, planes.npad, planes.q * 16, alpha, int(ref), _ptr(wt),
+                                int(pos_mode), _ptr(pm), _ptr(nm), _ptr(dist), _ptr(hist), _ptr(flags), _stream()),
+           "pg_index_flags")
+    return dist, hist, flags
+
+
+def compact_flags(flags):
+    """Ascending int64 indices of the non-zero entries of a uint8 device vector."""
+    L = lib()
+    n = flags.numel()
+    dev = flags.device
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    scratch = torch.empty(int(L.pg_scan_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+    _check(L.pg_compact_flags(_ptr(flags), n, _ptr(out), _ptr(cnt), _ptr(scratch), _stream()), "pg_compact_flags")
+    return out[: int(cnt.item())]
+
+
+def device_info():
+    L = lib()
+    device()
+    cus, wave = _i32(0), _i32(0)
+    arch = ctypes.create_string_buffer(64)
+    _check(L.pg_device_info(ctypes.byref(cus), ctypes.byref(wave), arch, 64), "pg_device_info")
+    return {"cus": cus.value, "wave": wave.value, "arch": arch.value.decode()}

@@ -1,0 +1,444 @@
+// C ABI of the hot path (include/prograph_hip.h) + the O(N*L) helper kernels:
+// plane packing, exclusive scan, flag compaction and the fused 1xN indexing pass.
+#include "pg_common.h"
+#include "../../include/prograph_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char *msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+static int hipfail(hipError_t e, const char *where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return (int)e;
+}
+static int launched(int rc, const char *where) {
+  if (rc != 0) return hipfail((hipError_t)rc, where);
+  return 0;
+}
+
+static MisK make_k() {
+  MisK k;
+  k.k7f = 0x7f7f7f7fu; k.k3f = 0x3f3f3f3fu; k.k1f = 0x1f1f1f1fu;
+  k.m80 = 0x80808080u; k.mc0 = 0xc0c0c0c0u; k.me0 = 0xe0e0e0e0u;
+  return k;
+}
+
+static int g_cus = 0;
+static int cu_count() {
+  if (g_cus > 0) return g_cus;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  g_cus = prop.multiProcessorCount;
+  return g_cus;
+}
+
+// waves per CU the all-pairs engine is sized for (PG_WAVES_PER_CU overrides; multiples of 4)
+static int waves_per_cu() {
+  const char *e = getenv("PG_WAVES_PER_CU");
+  int w = e ? atoi(e) : 8;
+  if (w < 4) w = 4;
+  if (w > 32) w = 32;
+  return (w / 4) * 4;
+}
+
+extern "C" {
+
+int pg_version(void) { return PG_ABI_VERSION; }
+const char *pg_last_error(void) { return g_err; }
+
+int pg_device_info(int *cus, int *wave, char *arch, int arch_len) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hipfail(e, "hipGetDevice");
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) return hipfail(e, "hipGetDeviceProperties");
+  if (cus) *cus = prop.multiProcessorCount;
+  if (wave) *wave = prop.warpSize;
+  if (arch && arch_len > 0) snprintf(arch, (size_t)arch_len, "%s", prop.gcnArchName);
+  return 0;
+}
+
+int64_t pg_npad(int64_t n) { return n <= 0 ? 256 : ((n + 255) / 256) * 256; }
+int pg_nplanes(int l) { return l <= 0 ? 1 : (l + 15) / 16; }
+
+}  // extern "C"
+
+// =======================================================================================
+// pack: row-major tokens -> planes
+// =======================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src, long long n, int l, long long ld,
+                                                      const long long *__restrict__ rows, uint4 *__restrict__ planes,
+                                                      long long npad, int nq, u32 *flags) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npad * nq) return;
+  const long long s = idx % npad;
+  const int q = (int)(idx / npad);
+  u32 w[4] = {0, 0, 0, 0};
+  u32 bad = 0;
+  if (s < n) {
+    const long long r = rows ? rows[s] : s;
+    const T *row = src + r * ld;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int pos = q * 16 + j;
+      if (pos < l) {
+        const long long v = (long long)row[pos];
+        if (v > 127) bad |= 1u;
+        if (v < 0 || v > 255) bad |= 2u;
+        w[j >> 2] |= ((u32)v & 0xffu) << (8 * (j & 3));
+      }
+    }
+  }
+  planes[(long long)q * npad + s] = make_uint4(w[0], w[1], w[2], w[3]);
+  if (bad) atomicOr(flags, bad);
+}
+
+// =======================================================================================
+// exclusive scan (u32 counts or u8 flags -> i64), three small kernels
+// =======================================================================================
+#define PG_SCAN_TILE 2048   // elements per block (256 threads x 8)
+
+template <typename T>
+__device__ __forceinline__ long long scan_val(const T *in, long long i, long long n) {
+  return i < n ? (long long)(in[i] != 0 ? (sizeof(T) == 1 ? 1 : in[i]) : 0) : 0;
+}
+
+__device__ __forceinline__ long long wave_incl_scan(long long v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    long long t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns the block total
+__device__ __forceinline__ long long block_excl_scan(long long v, long long &total) {
+  __shared__ long long wsum[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long inc = wave_incl_scan(v, lane);
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  long long base = 0;
+  for (int w = 0; w < wv; ++w) base += wsum[w];
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pg_scan_partials(const T *__restrict__ in, long long n, long long *partials) {
+  const long long b0 = (long long)blockIdx.x * PG_SCAN_TILE;
+  long long s = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += scan_val(in, b0 + threadIdx.x * 8 + j, n);
+  long long total;
+  block_excl_scan(s, total);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void pg_scan_single(long long *partials, long long nb) {
+  long long carry = 0;
+  for (long long c0 = 0; c0 < nb; c0 += 256) {
+    const long long i = c0 + threadIdx.x;
+    const long long v = i < nb ? partials[i] : 0;
+    long long total;
+    const long long ex = block_excl_scan(v, total);
+    if (i < nb) partials[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) partials[nb] = carry;
+}
+
+// MODE 0: out[i] = exclusive prefix (and out[n] = total); MODE 1: out[prefix] = i where in[i] != 0
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pg_scan_apply(const T *__restrict__ in, long long n, const long long *partials,
+                                                     long long nb, long long *out, long long *count) {
+  const long long b0 = (long long)blockIdx.x * PG_SCAN_TILE;
+  long long v[8], s = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { v[j] = scan_val(in, b0 + threadIdx.x * 8 + j, n); s += v[j]; }
+  long long total;
+  long long ex = block_excl_scan(s, total) + partials[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long long i = b0 + threadIdx.x * 8 + j;
+    if (i < n) {
+      if (MODE == 0) out[i] = ex;
+      else if (v[j]) out[ex] = i;
+    }
+    ex += v[j];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (MODE == 0) out[n] = partials[nb];
+    if (count) *count = partials[nb];
+  }
+}
+
+// =======================================================================================
+// fused 1xN indexing pass
+// =======================================================================================
+template <int ALPHA>
+__global__ __launch_bounds__(256) void pg_index_kernel(const uint4 *__restrict__ planes, long long n, long long npad, int nq,
+                                                       long long ref, const u32 *__restrict__ want, int posMode,
+                                                       const uint4 *__restrict__ posMask, const uint4 *__restrict__ notMask,
+                                                       unsigned char *distOut, u64 *hist, unsigned char *flags) {
+  __shared__ u32 lh[256];
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (s < n) {
+    u32 d = 0, anyP = 0, anyNot = 0;
+    bool allP = true;
+    for (int q = 0; q < nq; ++q) {
+      const uint4 c = planes[(long long)q * npad + s];
+      const uint4 r = planes[(long long)q * npad + ref];
+      const u32 f0 = mis_flags<ALPHA>(c.x, r.x), f1 = mis_flags<ALPHA>(c.y, r.y);
+      const u32 f2 = mis_flags<ALPHA>(c.z, r.z), f3 = mis_flags<ALPHA>(c.w, r.w);
+      d += __builtin_popcount(f0) + __builtin_popcount(f1) + __builtin_popcount(f2) + __builtin_popcount(f3);
+      if (posMode) {
+        const uint4 pm = posMask[q], nm = notMask[q];
+        anyP |= (f0 & pm.x) | (f1 & pm.y) | (f2 & pm.z) | (f3 & pm.w);
+        allP = allP && ((f0 & pm.x) == (0x80808080u & pm.x)) && ((f1 & pm.y) == (0x80808080u & pm.y)) &&
+               ((f2 & pm.z) == (0x80808080u & pm.z)) && ((f3 & pm.w) == (0x80808080u & pm.w));
+        anyNot |= (f0 & nm.x) | (f1 & nm.y) | (f2 & nm.z) | (f3 & nm.w);
+      }
+    }
+    if (distOut) distOut[s] = (unsigned char)d;
+    if (hist) atomicAdd(&lh[d & 255u], 1u);
+    if (flags) {
+      bool ok = want ? ((want[(d >> 5) & 7u] >> (d & 31u)) & 1u) != 0 : true;
+      if (posMode == 1) ok = ok && (anyP != 0) && (anyNot == 0);
+      if (posMode == 2) ok = ok && allP && (anyNot == 0);
+      flags[s] = ok ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (hist && lh[threadIdx.x]) atomicAdd((unsigned long long *)&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+// =======================================================================================
+// host side of the ABI
+// =======================================================================================
+static int check_l(int l) {
+  if (l <= 0) return fail(PG_E_BADARG, "sequence length must be positive");
+  if (l > PG_MAX_L) return fail(PG_E_TOOLONG, "sequence length exceeds PG_MAX_L (128 bytes)");
+  return 0;
+}
+static int check_alpha(int a) {
+  if (a != 5 && a != PG_ALPHA_7BIT && a != PG_ALPHA_8BIT) return fail(PG_E_BADARG, "alpha must be 5, 7 or 8");
+  return 0;
+}
+
+// comp(d, eps) & (d > 0) as an integer interval [lo, lo+span]; an empty interval is encoded
+// so that (d - lo) <= span is false for every d in 0..255
+static void eps_interval(int cmp, double eps, u32 *lo, u32 *span) {
+  const long long INF = 1000000;
+  long long l = 1, h = INF;
+  switch (cmp) {
+    case PG_CMP_LE: h = (long long)floor(eps); break;
+    case PG_CMP_LT: h = (long long)ceil(eps) - 1; break;
+    case PG_CMP_EQ:
+      if (floor(eps) == eps) { l = (long long)eps; h = (long long)eps; } else { l = 1; h = 0; }
+      break;
+    case PG_CMP_GE: l = (long long)ceil(eps); break;
+    case PG_CMP_GT: l = (long long)floor(eps) + 1; break;
+  }
+  if (l < 1) l = 1;
+  if (h > INF) h = INF;
+  if (h < l) { *lo = 0xFFFFFF00u; *span = 0; return; }
+  *lo = (u32)l;
+  *span = (u32)(h - l);
+}
+
+typedef int (*nsq_fn)(int, int, const NsqParams &, int, hipStream_t);
+typedef int (*dense_fn)(int, const DenseParams &, hipStream_t);
+typedef int (*compact_fn)(int, const CompactParams &, hipStream_t);
+static const nsq_fn kNsq[8] = {pg_launch_nsq_q1, pg_launch_nsq_q2, pg_launch_nsq_q3, pg_launch_nsq_q4,
+                               pg_launch_nsq_q5, pg_launch_nsq_q6, pg_launch_nsq_q7, pg_launch_nsq_q8};
+static const dense_fn kDense[8] = {pg_launch_dense_q1, pg_launch_dense_q2, pg_launch_dense_q3, pg_launch_dense_q4,
+                                   pg_launch_dense_q5, pg_launch_dense_q6, pg_launch_dense_q7, pg_launch_dense_q8};
+static const compact_fn kCompact[8] = {pg_launch_compact_q1, pg_launch_compact_q2, pg_launch_compact_q3,
+                                       pg_launch_compact_q4, pg_launch_compact_q5, pg_launch_compact_q6,
+                                       pg_launch_compact_q7, pg_launch_compact_q8};
+
+// Static, even split of the rows over the resident waves: every row costs the same (one
+// sweep over all columns), so equal row counts are equal work.  Each wave then walks its
+// rows in passes of at most PG_RB=16 rows of nearly equal size.
+static int plan_rows(int64_t nrows, NsqParams *p, int *grid) {
+  const int cus = cu_count();
+  if (cus <= 0) return fail(PG_E_NODEV, "no HIP device");
+  const long long maxWaves = (long long)cus * waves_per_cu();
+  long long rpw = (nrows + maxWaves - 1) / maxWaves;
+  if (rpw < 1) rpw = 1;
+  const long long waves = (nrows + rpw - 1) / rpw;
+  const long long passes = (rpw + 15) / 16;
+  p->rowsPerWave = (int)rpw;
+  p->rowsPerPass = (int)((rpw + passes - 1) / passes);
+  *grid = (int)((waves + PG_WG_WAVES - 1) / PG_WG_WAVES);
+  return 0;
+}
+
+extern "C" {
+
+int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld, const int64_t *rows, void *planes,
+                   int64_t npad, uint32_t *flags, void *stream) {
+  if (!src || !planes || !flags || n < 0 || ld < l) return fail(PG_E_BADARG, "pg_pack_planes: bad argument");
+  if (int rc = check_l(l)) return rc;
+  if (npad < n || npad % 256) return fail(PG_E_BADARG, "pg_pack_planes: npad must be pg_npad(n)");
+  const int nq = pg_nplanes(l);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t), s);
+  if (e != hipSuccess) return hipfail(e, "hipMemsetAsync");
+  const long long total = npad * nq;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  const long long *r = (const long long *)rows;
+  uint4 *pl = (uint4 *)planes;
+  switch (elem_bytes) {
+    case 1: pg_pack_kernel<unsigned char><<<grid, block, 0, s>>>((const unsigned char *)src, n, l, ld, r, pl, npad, nq, flags); break;
+    case 2: pg_pack_kernel<short><<<grid, block, 0, s>>>((const short *)src, n, l, ld, r, pl, npad, nq, flags); break;
+    case 4: pg_pack_kernel<int><<<grid, block, 0, s>>>((const int *)src, n, l, ld, r, pl, npad, nq, flags); break;
+    case 8: pg_pack_kernel<long long><<<grid, block, 0, s>>>((const long long *)src, n, l, ld, r, pl, npad, nq, flags); break;
+    default: return fail(PG_E_BADARG, "pg_pack_planes: elem_bytes must be 1, 2, 4 or 8");
+  }
+  return launched((int)hipGetLastError(), "pg_pack_kernel");
+}
+
+int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad, const void *y_planes, int64_t m, int64_t y_npad,
+                     int l, int alpha, void *out, int out_elem_bytes, int64_t ldo, void *stream) {
+  if (!x_planes || !y_planes || !out || n <= 0 || m <= 0 || ldo < n)
+    return fail(PG_E_BADARG, "pg_hamming_dense: bad argument");
+  if (int rc = check_l(l)) return rc;
+  if (int rc = check_alpha(alpha)) return rc;
+  if (out_elem_bytes != 1 && out_elem_bytes != 4 && out_elem_bytes != 8)
+    return fail(PG_E_BADARG, "pg_hamming_dense: out_elem_bytes must be 1, 4 or 8");
+  if (x_npad < n || x_npad % 256 || y_npad < m) return fail(PG_E_BADARG, "pg_hamming_dense: bad npad");
+  if ((m + PG_RBD - 1) / PG_RBD > 65535) return fail(PG_E_BADARG, "pg_hamming_dense: m too large for one launch");
+  DenseParams p;
+  p.K = make_k();
+  p.xPlanes = (const uint4 *)x_planes; p.xNpad = x_npad; p.n = n;
+  p.yPlanes = (const uint4 *)y_planes; p.yNpad = y_npad; p.m = m;
+  p.out = out; p.ldo = ldo; p.outBytes = out_elem_bytes;
+  return launched(kDense[pg_nplanes(l) - 1](alpha, p, (hipStream_t)stream), "pg_dense_kernel");
+}
+
+static int fill_nsq(NsqParams *p, const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
+                    const void *col_planes, int64_t col_npad, int64_t ncols, int l, int alpha) {
+  if (!row_planes || !col_planes || row0 < 0 || nrows <= 0 || ncols <= 0) return fail(PG_E_BADARG, "bad argument");
+  if (int rc = check_l(l)) return rc;
+  if (int rc = check_alpha(alpha)) return rc;
+  if (col_npad < ncols || col_npad % 256 || row_npad < row0 + nrows) return fail(PG_E_BADARG, "bad npad");
+  if (ncols > 0x7fffffffLL) return fail(PG_E_TOOMANY, "ncols exceeds int32 indices");
+  memset(p, 0, sizeof(*p));
+  p->K = make_k();
+  p->rowPlanes = (const uint4 *)row_planes; p->rowNpad = row_npad; p->row0 = row0; p->nrows = nrows;
+  p->colPlanes = (const uint4 *)col_planes; p->colNpad = col_npad; p->ncols = ncols;
+  return 0;
+}
+
+int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
+                 int64_t col_npad, int64_t ncols, int l, int alpha, int cmp, double eps, int cap, int32_t *slot_idx,
+                 uint8_t *slot_w, uint32_t *counts, void *stream) {
+  NsqParams p;
+  if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, alpha)) return rc;
+  if (!slot_idx || !slot_w || !counts || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
+    return fail(PG_E_BADARG, "pg_eps_slots: bad argument");
+  eps_interval(cmp, eps, &p.lo, &p.span);
+  p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
+  int grid = 0;
+  if (int rc = plan_rows(nrows, &p, &grid)) return rc;
+  return launched(kNsq[pg_nplanes(l) - 1](PG_MODE_EPS, alpha, p, grid, (hipStream_t)stream), "pg_nsq_kernel(eps)");
+}
+
+int64_t pg_scan_scratch_bytes(int64_t n) {
+  const int64_t nb = (n + PG_SCAN_TILE - 1) / PG_SCAN_TILE;
+  return (nb + 2) * (int64_t)sizeof(long long);
+}
+
+int pg_exclusive_scan(const uint32_t *counts, int64_t n, int64_t *indptr, void *scratch, void *stream) {
+  if (!counts || !indptr || !scratch || n <= 0) return fail(PG_E_BADARG, "pg_exclusive_scan: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const long long nb = (n + PG_SCAN_TILE - 1) / PG_SCAN_TILE;
+  long long *part = (long long *)scratch;
+  pg_scan_partials<u32><<<dim3((unsigned)nb), dim3(256), 0, s>>>(counts, n, part);
+  pg_scan_single<<<dim3(1), dim3(256), 0, s>>>(part, nb);
+  pg_scan_apply<u32, 0><<<dim3((unsigned)nb), dim3(256), 0, s>>>(counts, n, part, nb, (long long *)indptr, nullptr);
+  return launched((int)hipGetLastError(), "pg_scan");
+}
+
+int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
+                   int64_t col_npad, int64_t ncols, int l, int alpha, int cmp, double eps, int cap,
+                   const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts, const int64_t *indptr,
+                   int32_t *indices, uint8_t *weights, void *stream) {
+  CompactParams c;
+  if (int rc = fill_nsq(&c.e, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, alpha)) return rc;
+  if (!slot_idx || !slot_w || !counts || !indptr || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
+    return fail(PG_E_BADARG, "pg_eps_compact: bad argument");
+  eps_interval(cmp, eps, &c.e.lo, &c.e.span);
+  c.e.cap = (u32)cap;
+  c.e.slotIdx = const_cast<int *>(slot_idx);
+  c.e.slotW = const_cast<unsigned char *>(slot_w);
+  c.e.counts = const_cast<u32 *>(counts);
+  c.indptr = (const long long *)indptr; c.indices = indices; c.weights = weights;
+  return launched(kCompact[pg_nplanes(l) - 1](alpha, c, (hipStream_t)stream), "pg_compact_kernel");
+}
+
+int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
+                   int64_t col_npad, int64_t ncols, int l, int alpha, int k, int32_t *idx_out, uint8_t *dist_out,
+                   void *stream) {
+  NsqParams p;
+  if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, alpha)) return rc;
+  if (!idx_out || !dist_out) return fail(PG_E_BADARG, "pg_knn_hamming: bad argument");
+  if (k < 1 || k > PG_MAX_K) return fail(PG_E_BADARG, "pg_knn_hamming: k must be in 1..63");
+  if (ncols > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_knn_hamming: ncols exceeds 2^24");
+  p.k = k; p.knnIdx = idx_out; p.knnDist = dist_out;
+  int grid = 0;
+  if (int rc = plan_rows(nrows, &p, &grid)) return rc;
+  return launched(kNsq[pg_nplanes(l) - 1](PG_MODE_KNN, alpha, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");
+}
+
+int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int alpha, int64_t ref,
+                   const uint32_t *want_dist, int pos_mode, const uint8_t *pos_mask, const uint8_t *not_mask,
+                   uint8_t *dist_out, uint64_t *hist, uint8_t *flags, void *stream) {
+  if (!planes || n <= 0 || npad < n || ref < 0 || ref >= n) return fail(PG_E_BADARG, "pg_index_flags: bad argument");
+  if (int rc = check_l(l)) return rc;
+  if (int rc = check_alpha(alpha)) return rc;
+  if (pos_mode < 0 || pos_mode > 2 || (pos_mode && (!pos_mask || !not_mask)))
+    return fail(PG_E_BADARG, "pg_index_flags: bad position mode / masks");
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (alpha == PG_ALPHA_8BIT)
+    pg_index_kernel<8><<<grid, block, 0, s>>>((const uint4 *)planes, n, npad, pg_nplanes(l), ref, want_dist, pos_mode,
+                                              (const uint4 *)pos_mask, (const uint4 *)not_mask, dist_out,
+                                              (u64 *)hist, flags);
+  else
+    pg_index_kernel<7><<<grid, block, 0, s>>>((const uint4 *)planes, n, npad, pg_nplanes(l), ref, want_dist, pos_mode,
+                                              (const uint4 *)pos_mask, (const uint4 *)not_mask, dist_out,
+                                              (u64 *)hist, flags);
+  return launched((int)hipGetLastError(), "pg_index_kernel");
+}
+
+int pg_compact_flags(const uint8_t *flags, int64_t n, int64_t *out_idx, int64_t *out_count, void *scratch,
+                     void *stream) {
+  if (!flags || !out_idx || !out_count || !scratch || n <= 0) return fail(PG_E_BADARG, "pg_compact_flags: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const long long nb = (n + PG_SCAN_TILE - 1) / PG_SCAN_TILE;
+  long long *part = (long long *)scratch;
+  pg_scan_partials<unsigned char><<<dim3((unsigned)nb), dim3(256), 0, s>>>(flags, n, part);
+  pg_scan_single<<<dim3(1), dim3(256), 0, s>>>(part, nb);
+  pg_scan_apply<unsigned char, 1><<<dim3((unsigned)nb), dim3(256), 0, s>>>(flags, n, part, nb, (long long *)out_idx,
+                                                                          (long long *)out_count);
+  return launched((int)hipGetLastError(), "pg_compact_flags");
+}
+
+}  // extern "C"

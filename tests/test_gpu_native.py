@@ -1,0 +1,268 @@
+"""
+GPU parity tests through the C ABI (prograph_amd/_native.py -> libprograph_hip.so):
+HIP kernels vs (a) golden vectors generated from the real reference, (b) the oracle on
+seeded inputs, (c) size-independent properties at BASELINE.json's full sizes.
+Bit-exact: everything on this path is integer work.
+"""
+import operator
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+SETS = ["ref_synthetic_csv", "synth_n1000_l32", "synth_n2085_l64", "synth_n515_l20_dups", "synth_n300_varlen24"]
+ALPHAS = [5, 7, 8]
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from prograph_amd import _native
+    _native.lib()
+    _native.device()
+    return _native
+
+
+def _planes(nat, tok, alpha, rows=None):
+    p = nat.pack(torch.from_numpy(np.ascontiguousarray(tok)), rows=rows)
+    p.alpha = alpha
+    return p
+
+
+def _csr_np(t):
+    return [x.cpu().numpy() for x in t]
+
+
+@pytest.mark.parametrize("alpha", ALPHAS)
+@pytest.mark.parametrize("name", SETS)
+def test_eps_golden(nat, name, alpha):
+    g = load_golden(name)
+    tok = g["tokens"]
+    p = _planes(nat, tok, alpha)
+    for key in g.files:
+        if not key.endswith("_indptr") or "sub" in key or "sim" in key or "_b5" in key:
+            continue
+        base = key[:-7]
+        parts = base.split("_")
+        eps = int(parts[0][3:])
+        cmp = {"eq": nat.CMP_EQ, "lt": nat.CMP_LT, "ge": nat.CMP_GE, "gt": nat.CMP_GT}[parts[1]] if len(parts) > 1 else nat.CMP_LE
+        for cap in (256, 4):          # cap=4 forces the overflow/recompute path on almost every row
+            indptr, idx, w = _csr_np(nat.eps_graph(p, p, cmp, eps, cap=cap))
+            assert np.array_equal(indptr, g[base + "_indptr"]), (name, base, cap)
+            assert np.array_equal(idx, g[base + "_indices"]), (name, base, cap)
+            assert np.array_equal(w, g[base + "_weights"]), (name, base, cap)
+
+
+@pytest.mark.parametrize("alpha", ALPHAS)
+@pytest.mark.parametrize("name", SETS)
+def test_knn_golden(nat, name, alpha):
+    g = load_golden(name)
+    tok = g["tokens"]
+    p = _planes(nat, tok, alpha)
+    for key in g.files:
+        if not (key.startswith("knn") and key.endswith("_idx")) or "sub" in key or "sim" in key:
+            continue
+        k = int(key[3:-4])
+        idx, dist = nat.knn_graph(p, p, k)
+        assert np.array_equal(idx.cpu().numpy(), g[f"knn{k}_idx"]), (name, k)
+        assert np.array_equal(dist.cpu().numpy(), g[f"knn{k}_w"]), (name, k)
+
+
+def test_subgraph_rows_are_subset_relative(nat):
+    g = load_golden("synth_n515_l20_dups")
+    sub = g["sub_idxs"]
+    p = _planes(nat, g["tokens"], 7, rows=sub)
+    indptr, idx, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 2))
+    assert np.array_equal(indptr, g["eps2_sub_indptr"]) and np.array_equal(idx, g["eps2_sub_indices"])
+    assert np.array_equal(w, g["eps2_sub_weights"])
+    kidx, kd = nat.knn_graph(p, p, 3)
+    assert np.array_equal(kidx.cpu().numpy(), g["knn3_sub_idx"]) and np.array_equal(kd.cpu().numpy(), g["knn3_sub_w"])
+
+
+def test_row_window_equals_full(nat):
+    """Row-block sharding: rows [r0, r0+nr) computed alone equal that slice of the full result."""
+    g = load_golden("synth_n2085_l64")
+    p = _planes(nat, g["tokens"], 5)
+    indptr, idx, w = g["eps2_indptr"], g["eps2_indices"], g["eps2_weights"]
+    for r0, nr in [(0, 1), (1000, 77), (2000, 85), (261, 1042)]:
+        ip, ix, ww = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 2, row0=r0, nrows=nr))
+        assert np.array_equal(ip, indptr[r0:r0 + nr + 1] - indptr[r0])
+        assert np.array_equal(ix, idx[indptr[r0]:indptr[r0 + nr]])
+        assert np.array_equal(ww, w[indptr[r0]:indptr[r0 + nr]])
+        kidx, kd = nat.knn_graph(p, p, 16, row0=r0, nrows=nr)
+        assert np.array_equal(kidx.cpu().numpy(), g["knn16_idx"][r0:r0 + nr])
+        assert np.array_equal(kd.cpu().numpy(), g["knn16_w"][r0:r0 + nr])
+
+
+def test_dense_kats(nat):
+    g = load_golden("hamming_kats")
+    for i in range(4):       # r4/r5 exceed 128 tokens: not a native shape
+        X, Y = g[f"r{i}_X"], g[f"r{i}_Y"]
+        D = max(X.shape[1], Y.shape[1])
+        Xp = np.zeros((X.shape[0], D), np.uint8); Xp[:, :X.shape[1]] = X
+        Yp = np.zeros((Y.shape[0], D), np.uint8); Yp[:, :Y.shape[1]] = Y
+        for alpha in ALPHAS:
+            out = nat.hamming_dense(_planes(nat, Xp, alpha), _planes(nat, Yp, alpha))
+            assert out.dtype == torch.int64 and np.array_equal(out.cpu().numpy(), g[f"r{i}_out"])
+    X, Y = g["wide_X"], g["wide_Y"]
+    xp, yp = nat.pack(torch.from_numpy(X)), nat.pack(torch.from_numpy(Y))
+    assert xp.alpha == 8 or yp.alpha == 8
+    assert np.array_equal(nat.hamming_dense(xp, yp).cpu().numpy(), g["wide_out"])
+    for ob, dt in [(1, torch.uint8), (4, torch.int32)]:
+        out = nat.hamming_dense(xp, yp, out_bytes=ob)
+        assert out.dtype == dt and np.array_equal(out.cpu().numpy().astype(np.int64), g["wide_out"])
+
+
+def test_dense_vs_oracle_all_q(nat):
+    from oracle import prograph_oracle as O
+    rng = np.random.RandomState(5)
+    for L in [1, 3, 16, 17, 31, 33, 48, 64, 65, 80, 96, 100, 112, 127, 128]:
+        X = rng.randint(0, 21, size=(300, L)).astype(np.uint8)
+        Y = X[rng.randint(0, 300, size=70)].copy()
+        Y[:, rng.randint(0, L)] = 0
+        ref = O.hamming(X.astype(np.int64), Y.astype(np.int64)).numpy()
+        for alpha in ALPHAS:
+            out = nat.hamming_dense(_planes(nat, X, alpha), _planes(nat, Y, alpha))
+            assert np.array_equal(out.cpu().numpy(), ref), (L, alpha)
+
+
+def test_engine_vs_oracle_all_q(nat):
+    """eps + kNN engines against the oracle for every chunk count Q=1..8 (L up to 128)."""
+    from oracle import prograph_oracle as O
+    from prograph_amd import synth
+    for L in [5, 16, 24, 40, 50, 64, 70, 90, 100, 128]:
+        tok = synth.clustered_tokens(700, L, seed=100 + L, members=100)
+        tok[13] = tok[400]
+        ref_e = O.neighbours_to_csr(O.build_graph(tok.astype(np.int64), eps=3))
+        ref_k = O.neighbours_to_knn(O.build_graph(tok.astype(np.int64), k=7))
+        for alpha in ALPHAS:
+            p = _planes(nat, tok, alpha)
+            ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 3))
+            assert np.array_equal(ip, ref_e[0]) and np.array_equal(ix, ref_e[1]) and np.array_equal(w, ref_e[2]), (L, alpha)
+            kidx, kd = nat.knn_graph(p, p, 7)
+            assert np.array_equal(kidx.cpu().numpy(), ref_k[0]) and np.array_equal(kd.cpu().numpy(), ref_k[1]), (L, alpha)
+
+
+def test_knn_edge_cases(nat):
+    from oracle import prograph_oracle as O
+    rng = np.random.RandomState(9)
+    # N smaller than k+1: missing ranks are -1 / 255; identical rows; k at the maximum
+    tok = rng.randint(1, 21, size=(5, 12)).astype(np.uint8)
+    p = _planes(nat, tok, 7)
+    idx, d = nat.knn_graph(p, p, 8)
+    idx, d = idx.cpu().numpy(), d.cpu().numpy()
+    ref = O.neighbours_to_knn(O.build_graph(tok.astype(np.int64), k=8))
+    assert np.array_equal(idx[:, :4], ref[0]) and np.array_equal(d[:, :4], ref[1])
+    assert np.all(idx[:, 4:] == -1) and np.all(d[:, 4:] == 255)
+    tok = np.repeat(rng.randint(1, 21, size=(1, 20)), 300, axis=0).astype(np.uint8)
+    p = _planes(nat, tok, 5)
+    idx, d = nat.knn_graph(p, p, 63)
+    ref = O.neighbours_to_knn(O.build_graph(tok.astype(np.int64), k=63))
+    assert np.array_equal(idx.cpu().numpy(), ref[0]) and np.all(d.cpu().numpy() == 0)
+    ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 5))
+    assert ip[-1] == 0 and len(ix) == 0          # duplicates are d == 0: excluded (prograph.py:736)
+
+
+def test_eps_float_thresholds_and_comparators(nat):
+    from oracle import prograph_oracle as O
+    g = load_golden("synth_n515_l20_dups")
+    tok = g["tokens"]
+    p = _planes(nat, tok, 7)
+    for op, code in [(operator.le, nat.CMP_LE), (operator.lt, nat.CMP_LT), (operator.eq, nat.CMP_EQ),
+                     (operator.ge, nat.CMP_GE), (operator.gt, nat.CMP_GT)]:
+        for eps in (1, 2.5, 3, 19, 20, 21, 300):
+            ref = O.neighbours_to_csr(O.build_graph(tok.astype(np.int64), eps=eps, comp=op))
+            ip, ix, w = _csr_np(nat.eps_graph(p, p, code, eps, cap=64))
+            assert np.array_equal(ip, ref[0]) and np.array_equal(ix, ref[1]) and np.array_equal(w, ref[2].astype(np.uint8)), (op, eps)
+
+
+def test_index_flags_and_compaction(nat):
+    g = load_golden("ref_synthetic_csv")
+    tok = g["tokens"]
+    p = _planes(nat, tok, 7)
+    dist, hist, _ = nat.index_flags(p, 0, want_flags=False)
+    assert np.array_equal(dist.cpu().numpy(), g["dist_to_seed"][0])
+    assert np.array_equal(hist.cpu().numpy(), np.bincount(g["dist_to_seed"][0], minlength=256))
+    _, _, fl = nat.index_flags(p, 0, want=[3], want_dist_out=False, want_hist=False)
+    assert np.array_equal(nat.compact_flags(fl).cpu().numpy(), g["ix_d3"])
+    _, _, fl = nat.index_flags(p, 0, want=[1, 3], want_dist_out=False, want_hist=False)
+    assert np.array_equal(nat.compact_flags(fl).cpu().numpy(), g["ix_d13"])
+    pm = np.zeros(16, np.uint8); nm = np.zeros(16, np.uint8)
+    pm[[1, 2]] = 0xFF; nm[[0]] = 0xFF
+    for mode, key in [(1, "ix_pos12"), (2, "ix_pos12_and")]:
+        _, _, fl = nat.index_flags(p, 0, pos_mode=mode, pos_mask=pm, not_mask=nm, want_dist_out=False, want_hist=False)
+        assert np.array_equal(nat.compact_flags(fl).cpu().numpy(), g[key])
+    _, _, fl = nat.index_flags(p, 0, want=[2], pos_mode=1, pos_mask=pm, not_mask=nm, want_dist_out=False, want_hist=False)
+    assert np.array_equal(nat.compact_flags(fl).cpu().numpy(), g["ix_pos12_d2"])
+    pm[:] = 0; nm[:] = 0; pm[1] = 0xFF; nm[[0, 2]] = 0xFF
+    _, _, fl = nat.index_flags(p, int(g["LDC_idx"]), pos_mode=1, pos_mask=pm, not_mask=nm, want_dist_out=False, want_hist=False)
+    assert np.array_equal(nat.compact_flags(fl).cpu().numpy(), g["ix_LDC_pos1"])
+    # compaction at a size that spans many scan tiles
+    rng = np.random.RandomState(1)
+    f = (rng.rand(1_000_003) < 0.3).astype(np.uint8)
+    got = nat.compact_flags(torch.from_numpy(f).cuda()).cpu().numpy()
+    assert np.array_equal(got, np.nonzero(f)[0])
+
+
+def test_pack_flags_and_errors(nat):
+    tok = np.array([[1, 2, 200], [3, 4, 5]], dtype=np.int64)
+    assert nat.pack(torch.from_numpy(tok)).alpha == 8
+    with pytest.raises(ValueError):
+        nat.pack(torch.from_numpy(np.array([[1, 2, 300]], dtype=np.int64)))
+    with pytest.raises(ValueError):
+        nat.pack(torch.from_numpy(np.array([[1, -2, 3]], dtype=np.int64)))
+    with pytest.raises(ValueError):
+        nat.pack(torch.zeros((4, 129), dtype=torch.uint8))
+    p = nat.pack(torch.ones((10, 8), dtype=torch.uint8))
+    with pytest.raises(RuntimeError):
+        nat.knn_graph(p, p, 64)
+    with pytest.raises(RuntimeError):
+        nat.knn_graph(p, p, 0)
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_full_size_properties(nat, cfg):
+    """
+    BASELINE.json configs[1] / configs[2] at full size, checked through properties that do not
+    need an N^2 oracle: (i) CSR symmetry with equal weights (Hamming is symmetric), (ii) every
+    row's columns strictly ascending, no self/duplicate (d >= 1), (iii) kNN rows are sorted by
+    (d, idx), (iv) a random sample of rows equals the oracle's 1xN computation exactly,
+    (v) eps-degree equals the count of kNN-consistent distances on sampled rows.
+    """
+    from oracle import prograph_oracle as O
+    from prograph_amd import synth
+    N, L, eps, k = (50_000, 32, 2, 16) if cfg == "cfg2" else (200_000, 64, 2, 16)
+    tok = synth.clustered_tokens(N, L)
+    p = nat.refine_alpha(nat.pack(torch.from_numpy(tok)), 20)
+    assert p.alpha == 5
+    indptr, idx, w = nat.eps_graph(p, p, nat.CMP_LE, eps, cap=256)
+    kidx, kd = nat.knn_graph(p, p, k)
+    torch.cuda.synchronize()
+    indptr, idx, w = indptr.cpu().numpy(), idx.cpu().numpy().astype(np.int64), w.cpu().numpy()
+    kidx, kd = kidx.cpu().numpy().astype(np.int64), kd.cpu().numpy()
+    rows = np.repeat(np.arange(N), np.diff(indptr))
+    assert w.min() >= 1 and w.max() <= eps
+    # ascending columns inside each row
+    same = rows[1:] == rows[:-1]
+    assert np.all(idx[1:][same] > idx[:-1][same])
+    # symmetry: the multiset of (row, col, w) equals that of (col, row, w)
+    a = np.sort(rows * N + idx); b = np.sort(idx * N + rows)
+    assert np.array_equal(a, b)
+    key_f = (rows * N + idx) * 256 + w; key_b = (idx * N + rows) * 256 + w
+    assert np.array_equal(np.sort(key_f), np.sort(key_b))
+    # kNN rows sorted by (d, idx)
+    kk = kd.astype(np.int64) * (1 << 24) + kidx
+    assert np.all(kk[:, 1:] > kk[:, :-1]) and kidx.min() >= 0 and kidx.max() < N
+    # sampled rows against the oracle (1 x N per row: cheap)
+    rs = np.random.RandomState(0).choice(N, size=24, replace=False)
+    t64 = tok.astype(np.int64)
+    for r in rs:
+        d = O.hamming(t64, t64[r].reshape(1, -1)).numpy()[0]
+        cols = np.where((d <= eps) & (d > 0))[0]
+        assert np.array_equal(idx[indptr[r]:indptr[r + 1]], cols)
+        assert np.array_equal(w[indptr[r]:indptr[r + 1]], d[cols])
+        order = np.argsort(d, kind="stable")[1:k + 1]
+        assert np.array_equal(kidx[r], order) and np.array_equal(kd[r], d[order])
