@@ -1,0 +1,105 @@
+/*
+ * ORACLE (C leg) — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain C restatement of the reference's hot path (acmater/prograph; citations into
+ * /root/reference) for sizes where the Python oracle (oracle/prograph_oracle.py) is too slow.
+ * Pinned: tests/test_oracle.py checks every function here against the Python oracle, which is
+ * itself pinned to golden vectors generated from the real reference.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ *   orc_hamming   d[m][n] = #{j : Y[m][j] != X[n][j]}            prograph/distance/hamming.py:34
+ *   orc_eps       (comp(d,eps) & (d>0)) per row, columns ascending prograph/prograph.py:731-753
+ *   orc_knn       stable ascending sort by distance, ranks 1..k    prograph/prograph.py:756-764
+ *   orc_synth     the deterministic generator of prograph_amd/synth.py
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int ham(const uint8_t *a, const uint8_t *b, int l) {
+  int d = 0;
+  for (int j = 0; j < l; ++j) d += a[j] != b[j];
+  return d;
+}
+
+void orc_hamming(const uint8_t *X, int64_t n, const uint8_t *Y, int64_t m, int l, int64_t *out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < m; ++r)
+    for (int64_t c = 0; c < n; ++c) out[r * n + c] = ham(Y + r * l, X + c * l, l);
+}
+
+static inline int cmp_ok(int cmp, double d, double eps) {
+  switch (cmp) {
+    case 0: return d <= eps;
+    case 1: return d < eps;
+    case 2: return d == eps;
+    case 3: return d >= eps;
+    default: return d > eps;
+  }
+}
+
+/* pass 1 (indices == NULL): counts[r]; pass 2: fill indices/weights at indptr[r] */
+void orc_eps(const uint8_t *T, int64_t n, int l, int64_t row0, int64_t nrows, int cmp, double eps,
+             int64_t *counts, const int64_t *indptr, int32_t *indices, uint8_t *weights) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t r = 0; r < nrows; ++r) {
+    const uint8_t *a = T + (row0 + r) * l;
+    int64_t k = 0, base = indices ? indptr[r] : 0;
+    for (int64_t c = 0; c < n; ++c) {
+      int d = ham(a, T + c * l, l);
+      if (d > 0 && cmp_ok(cmp, (double)d, eps)) {
+        if (indices) { indices[base + k] = (int32_t)c; weights[base + k] = (uint8_t)d; }
+        ++k;
+      }
+    }
+    if (!indices) counts[r] = k;
+  }
+}
+
+/* canonical kNN: k+1 smallest (d, column), rank 0 dropped; missing ranks -> -1 / 255 */
+void orc_knn(const uint8_t *T, int64_t n, int l, int64_t row0, int64_t nrows, int k, int32_t *idx, uint8_t *dist) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t r = 0; r < nrows; ++r) {
+    const uint8_t *a = T + (row0 + r) * l;
+    int64_t best[65];
+    int nb = 0;
+    for (int64_t c = 0; c < n; ++c) {
+      int64_t key = ((int64_t)ham(a, T + c * l, l) << 32) | c;
+      if (nb == k + 1 && key >= best[nb - 1]) continue;
+      int p = nb < k + 1 ? nb++ : nb - 1;
+      while (p > 0 && best[p - 1] > key) { best[p] = best[p - 1]; --p; }
+      best[p] = key;
+    }
+    for (int j = 0; j < k; ++j) {
+      if (j + 1 < nb) { idx[r * k + j] = (int32_t)(best[j + 1] & 0xffffffff); dist[r * k + j] = (uint8_t)(best[j + 1] >> 32); }
+      else { idx[r * k + j] = -1; dist[r * k + j] = 255; }
+    }
+  }
+}
+
+static inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static inline uint64_t hh(uint64_t seed, uint64_t stream, uint64_t i) {
+  return mix64(seed + 0x9E3779B97F4A7C15ULL * (4 * i + stream + 1));
+}
+
+void orc_synth(int64_t n, int l, uint64_t seed, int64_t members, uint8_t *out) {
+  int64_t nc = n / members;
+  if (nc < 1) nc = 1;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t c = i % nc;
+    uint8_t *row = out + i * l;
+    for (int j = 0; j < l; ++j) row[j] = (uint8_t)(1 + hh(seed, 0, (uint64_t)(c * l + j)) % 20);
+    int m = 1 + (int)(hh(seed, 1, (uint64_t)i) % 3);
+    /* positions and steps are drawn from the UNMUTATED row index stream; substitutions apply in
+       order t = 0,1,2 and each reads the token as left by the previous ones */
+    for (int t = 0; t < m; ++t) {
+      int pos = (int)(hh(seed, 2, (uint64_t)(8 * i + t)) % (uint64_t)l);
+      int step = (int)(hh(seed, 3, (uint64_t)(8 * i + t)) % 19);
+      row[pos] = (uint8_t)(1 + ((row[pos] - 1 + 1 + step) % 20));
+    }
+  }
+}

@@ -102,7 +102,7 @@ def _validate(eps, k):
 # a5 / a7  build_graph                                   prograph/prograph.py:656-765
 # --------------------------------------------------------------------------------------
 def build_graph(tokens, idxs=None, batch_size=8, eps=None, k=None, similarity=False,
-                distance=hamming, comp=operator.le, stable=True, dtype=torch.float16):
+                distance=hamming, comp=operator.le, stable=True, dtype=torch.float16, row_limit=None):
     """
     Restates both branches of `build_graph`.  `tokens` is the (N, L) representation the
     reference fetches with `self(representation)`; it is cast to fp16 exactly as
@@ -111,6 +111,9 @@ def build_graph(tokens, idxs=None, batch_size=8, eps=None, k=None, similarity=Fa
     `stable=True` is the build's canonical kNN tie rule (SURVEY.md §7 hard part 2): the
     reference's `torch.sort` at :758-760 is unstable, so with integer distances its
     *indices* are implementation defined; weights are not.
+
+    `row_limit=R` walks only the batches of the first R rows (against all columns): the bounded
+    sample bench.py times as the CPU baseline; the per-batch work is unchanged.
     """
     _validate(eps, k)
     if similarity and eps:
@@ -119,8 +122,9 @@ def build_graph(tokens, idxs=None, batch_size=8, eps=None, k=None, similarity=Fa
     if idxs is not None:
         X = X[idxs, :]
     weights, edge_idxs = [], []
+    R = X if row_limit is None else X[:row_limit]
     if eps:
-        for batch in list(get_every_n(X, n=batch_size)):         # :731
+        for batch in list(get_every_n(R, n=batch_size)):         # :731
             d = distance(X, batch, similarity=similarity)        # :732
             if similarity:
                 loc = torch.where(comp(eps, d) & (d < 1))        # :734
@@ -132,8 +136,8 @@ def build_graph(tokens, idxs=None, batch_size=8, eps=None, k=None, similarity=Fa
                  for i, r in enumerate(edge_idxs)]               # :743-745
         nd = {kk: v for d_ in final for kk, v in d_.items()}     # :748
         return [nd.get(i, (np.array([], dtype=int), np.array([], dtype=int)))
-                for i in range(len(X))]                          # :751-753
-    for batch in list(get_every_n(X, n=batch_size)):             # :756
+                for i in range(len(R))]                          # :751-753
+    for batch in list(get_every_n(R, n=batch_size)):             # :756
         d = distance(X, batch, similarity=similarity)
         s = torch.sort(d, dim=1, descending=bool(similarity), stable=stable)   # :758-760
         weights.append([x.numpy() for x in s[0][:, 1:k + 1]])    # :761

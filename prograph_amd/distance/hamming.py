@@ -1,0 +1,50 @@
+"""
+Hamming distance operator — the reference's plug-in contract
+`distance(X (N,D), Y (M,D), similarity=False) -> (M,N)` (prograph/distance/hamming.py:8-39),
+computed by the HIP dense kernel (`pg_hamming_dense`) instead of the broadcast
+`torch.sum(X != Y[:,None,:], axis=2)`.
+
+Same conventions as the reference: the result is (M, N) — row m is Y[m] against every row
+of X (the reference's docstring says N x M, its code and tests say M x N) — `torch.int64`,
+on the device of the inputs; `ValueError` on an empty operand; zero right-padding when the
+second dimensions differ; `similarity=True` returns 1/(1+d).
+
+Byte tokens (integer valued, 0..255, D <= 128) take the native kernel.  Anything else is not
+tokenised sequence data (floats with fractions, wide integers, D > 128) and is evaluated
+with the same torch expression as the reference, on the GPU; there is no CPU path.
+"""
+import torch
+
+from .. import _native
+from .utils import clean_input
+
+
+def _as_byte_tokens(T):
+    """uint8 view of an integer valued tensor in 0..255, or None."""
+    if T.dtype == torch.uint8:
+        return T
+    if T.dtype == torch.bool:
+        return T.to(torch.uint8)
+    if T.is_floating_point():
+        ok = torch.isfinite(T).all() and (T == T.floor()).all() and (T >= 0).all() and (T <= 255).all()
+    else:
+        ok = (T >= 0).all() and (T <= 255).all()
+    return T.to(torch.uint8) if bool(ok) else None
+
+
+def hamming(X, Y, similarity=False):
+    X, Y = clean_input(X, Y)
+    home = X.device
+    dev = _native.device()
+    Xd, Yd = X.to(dev), Y.to(dev)
+    xb = yb = None
+    if X.shape[1] <= _native.MAX_L:
+        xb = _as_byte_tokens(Xd)
+        yb = _as_byte_tokens(Yd) if xb is not None else None
+    if xb is not None and yb is not None:
+        distances = _native.hamming_dense(_native.pack(xb), _native.pack(yb), out_bytes=8)
+    else:
+        distances = torch.sum(Xd != Yd[:, None, :], axis=2)
+    if similarity:
+        distances = 1 / (1 + distances)
+    return distances.to(home)

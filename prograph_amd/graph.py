@@ -1,0 +1,90 @@
+"""
+Result containers of the graph-construction path.
+
+The reference hands back a Python list of N `(indices, weights)` tuples per graph
+(prograph/prograph.py:751-753, :764) and stores it in a DataFrame column.  The HIP path
+produces CSR / (N,k) arrays on the device; these classes keep that form (device resident,
+no per-row Python objects) and materialise the reference's tuples only on request, as
+zero-copy views into two host arrays.
+"""
+import numpy as np
+import torch
+
+
+class CSRGraph:
+    """epsilon-neighbourhood graph: indptr int64 [n+1], indices int32 [nnz], weights uint8|float32 [nnz]."""
+
+    def __init__(self, indptr, indices, weights, ncols, similarity=False, row0=0):
+        self.indptr, self.indices, self.weights = indptr, indices, weights
+        self.ncols, self.similarity, self.row0 = int(ncols), bool(similarity), int(row0)
+
+    @property
+    def nrows(self):
+        return int(self.indptr.numel() - 1)
+
+    @property
+    def nnz(self):
+        return int(self.indices.numel())
+
+    def host(self):
+        """(indptr, indices int64, weights) as numpy, weights in the reference's dtype:
+        int64 Hamming distances, or float32 similarities 1/(1+d) (hamming.py:38)."""
+        indptr = self.indptr.cpu().numpy()
+        idx = self.indices.to(torch.int64).cpu().numpy()
+        if self.similarity:
+            w = (1 / (1 + self.weights.to(torch.int64))).cpu().numpy()
+        else:
+            w = self.weights.to(torch.int64).cpu().numpy()
+        return indptr, idx, w
+
+    def to_tuples(self):
+        """list of N (np.int64 indices ascending, weights) — the reference's `Neighbours` format.
+        Rows without neighbours get `(array([], int), array([], int))` (prograph.py:753)."""
+        indptr, idx, w = self.host()
+        out = []
+        for a, b in zip(indptr[:-1].tolist(), indptr[1:].tolist()):
+            out.append((idx[a:b], w[a:b]) if b > a else (np.array([], dtype=int), np.array([], dtype=int)))
+        return out
+
+    def degree(self, boolean_weights=False):
+        """Out-degree per row as float32 (prograph.py:797-822) without touching Python tuples."""
+        counts = (self.indptr[1:] - self.indptr[:-1])
+        if boolean_weights:
+            return counts.to(torch.float32).cpu().numpy()
+        if self.similarity:
+            w = (1 / (1 + self.weights.to(torch.int64))).to(torch.float32)
+        else:
+            w = self.weights.to(torch.float32)
+        rows = torch.repeat_interleave(torch.arange(self.nrows, device=w.device), counts)
+        return torch.zeros(self.nrows, dtype=torch.float32, device=w.device).index_add_(0, rows, w).cpu().numpy()
+
+    def coords(self, boolean_weights=False):
+        """(I, J, V) of prograph.py:824-857 straight from CSR."""
+        indptr, idx, w = self.host()
+        I = np.repeat(np.arange(self.nrows, dtype=int) + self.row0, np.diff(indptr))
+        if boolean_weights:
+            return I, idx, np.ones(I.shape)
+        return I, idx, w.astype(np.float32)
+
+
+class KNNGraph:
+    """k nearest neighbours: idx int32 (n,k), dist uint8 (n,k); canonical (distance, index) order."""
+
+    def __init__(self, idx, dist, ncols, similarity=False, row0=0):
+        self.idx, self.dist = idx, dist
+        self.ncols, self.similarity, self.row0 = int(ncols), bool(similarity), int(row0)
+
+    @property
+    def nrows(self):
+        return int(self.idx.shape[0])
+
+    def host(self):
+        kk = min(self.idx.shape[1], max(self.ncols - 1, 0))    # ranks beyond N-1 do not exist ([:,1:k+1])
+        idx = self.idx[:, :kk].to(torch.int64).cpu().numpy()
+        d = self.dist[:, :kk].to(torch.int64)
+        w = (1 / (1 + d)).cpu().numpy() if self.similarity else d.cpu().numpy()
+        return idx, w
+
+    def to_tuples(self):
+        idx, w = self.host()
+        return list(zip(list(idx), list(w)))

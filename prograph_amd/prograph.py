@@ -1,0 +1,584 @@
+"""
+`Prograph` — host-side mirror of the reference's class (prograph/prograph.py of
+acmater/prograph) with the graph-construction hot path running on hand-written HIP kernels.
+
+Same constructor, same methods, same return conventions, so code written against the
+reference keeps working; what changed is *where the work happens*:
+
+  reference (prograph/prograph.py)                     here
+  -----------------------------------------------      ------------------------------------
+  :726  list-of-arrays -> fp16 tensor on cuda:0        int8 plane layout, packed on device once
+  :731-739 batches of 8: broadcast !=, sum, where,     one `pg_eps_slots` launch + scan +
+           3 D->H copies and a sync per batch          `pg_eps_compact`; one sync in total
+  :756-762 full torch.sort per row                     `pg_knn_hamming` (in-register top-(k+1))
+  :298-325 1xN hamming + numpy set logic               `pg_index_flags` + `pg_compact_flags`
+
+There is no CPU fallback for that path: without the HIP library or a GPU the calls raise
+`prograph_amd._native.NativeUnavailable`.  A custom `distance` callable, a `comp` outside the
+five orderings, non-byte representations (e.g. fp16 embeddings with `minkowski`), k > 63 or
+L > 128 go through `_build_graph_generic`, which is the reference's batch loop kept on torch
+ops on the GPU — the distance-operator protocol stays pluggable.
+
+kNN tie rule: the reference's `torch.sort` (:758-760) is unstable, so with integer distances
+its neighbour *indices* are implementation defined.  This implementation fixes the canonical
+order (distance, index) == `torch.sort(stable=True)`, drops rank 0 like the reference does
+and returns ranks 1..k.  Weights are bit-identical to the reference either way.
+"""
+import copy
+import operator
+from functools import reduce
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import _native
+from .distance import hamming, minkowski
+from .graph import CSRGraph, KNNGraph
+from .protein import Protein
+from .utils import Dataset, save, flatten
+
+_CMP_CODE = {operator.le: _native.CMP_LE, operator.lt: _native.CMP_LT, operator.eq: _native.CMP_EQ,
+             operator.ge: _native.CMP_GE, operator.gt: _native.CMP_GT}
+_DEFAULT_SCALER = object()      # "use sklearn's MinMaxScaler" without importing sklearn at module import
+
+
+class Prograph:
+    def __init__(self, file, seed_seq=None, seqs_col="Sequence", columns=["Fitness"], index_col=0,
+                 amino_acids="ACDEFGHIKLMNPQRSTVWY"):
+        try:
+            ext = file.split(".")[-1]
+            if ext == "csv":
+                self.graph = self.csvDataLoader(file, seqs_col=seqs_col, columns=columns, index_col=index_col)
+            elif ext == "pkl":
+                self.graph = pd.read_pickle(file)
+            else:
+                raise ValueError(ext)
+        except Exception:
+            # the reference turns every load problem (missing file, file=None, file=2, ...) into this
+            raise FileNotFoundError("File could not be opened")
+
+        self.file, self.seed_seq, self.seqs_col = file, seed_seq, seqs_col
+        self.columns, self.index_col, self.amino_acids = columns, index_col, amino_acids
+
+        self.seed = Protein(seed_seq) if seed_seq else Protein(**self.graph.loc[0])
+        self.seq_len = len(self.seed)
+        self.len = len(self)
+
+        self.tokens = {aa.encode("utf-8"): i for i, aa in enumerate(self.amino_acids, start=1)}
+        self.tokenized = self.tokenize(self.graph[seqs_col])
+        self._planes = {}            # device-resident plane layouts, keyed by representation
+        self._token_dict = None
+        self.seq_idxs = dict(zip(self.graph[seqs_col], range(len(self.graph))))   # last duplicate wins
+
+        self.mutated_positions = self.calc_mutated_positions()
+        self.sequence_mutation_locations = self.boolean_mutant_array(self.seed.Sequence)
+        self.mutation_arrays = self.gen_mutation_arrays()
+        self.csr_graphs = {}         # name -> CSRGraph / KNNGraph kept on the device
+
+        if "Tokenized" not in self.graph:
+            self.graph["Tokenized"] = list(self.tokenized)
+        if "Neighbours" not in self.graph:
+            self.graph["Neighbours"] = self.build_graph(eps=1, _keep="Neighbours")
+
+        self.learners = {}
+        print(self)
+
+    # ------------------------------------------------------------------ dunder / query surface
+    def __str__(self):
+        hist = self._distance_histogram(self.seed.Sequence)
+        present = np.nonzero(hist)[0]
+        longest = max((len(s) for s in self("Sequence")), default=0)
+        return f"""
+            Prograph
+            Number of Sequences : {len(self)}
+            Max Distance        : {int(present[-1])}
+            Longest Sequence    : {longest}
+            Number of Distances : {len(present)}
+            Seed Sequence       : {self.coloured_seed_string()}
+                Modified positions are shown in green"""
+
+    def __repr__(self):
+        return (f"Prograph(file={self.file},\n seed_seq='{self.seed.Sequence}',\n seqs_col='{self.seqs_col}',\n"
+                f" columns={self.columns},\n index_col={self.index_col},\n amino_acids='{self.amino_acids}')")
+
+    def __len__(self):
+        return len(self.graph)
+
+    def __getitem__(self, idx):
+        return self.graph.iloc[self.query(idx)]
+
+    def __call__(self, label=None, **kwargs):
+        return self.label_iter(label, **kwargs)
+
+    def label_iter(self, label, **kwargs):
+        """`pgraph("Sequence")`, `pgraph("sklearn", ...)`, `pgraph("pytorch", ...)`, `pgraph()`; copies."""
+        if label == "pytorch":
+            return self.pytorch_dataloaders(**kwargs)
+        if label == "sklearn":
+            return self.sklearn_data(**kwargs)
+        if label is None:
+            return self.graph.copy()
+        return self.graph[label].copy()
+
+    @property
+    def token_dict(self):
+        """{tuple(tokens): index}; built on first use (O(N*L) Python objects, unused by the hot path)."""
+        if self._token_dict is None:
+            self._token_dict = {tuple(seq): i for i, seq in enumerate(self.tokenized)}
+        return self._token_dict
+
+    def query(self, sequence):
+        """int / str / token tuple / list or array of those -> positional index (reference :204-240)."""
+        missing = "This sequence is not in the dataset."
+        if isinstance(sequence, (int, np.integer)):
+            assert sequence <= self.len, "Index exceeds bounds of dataset"
+            return sequence
+        if isinstance(sequence, (np.ndarray, list)):
+            first = sequence[0]
+            if isinstance(first, (int, np.integer, np.bool_)):
+                return sequence
+            if isinstance(first, str):
+                return [self.seq_idxs.get(s, missing) for s in sequence]
+            print("Wrong data format in numpy array or list iterable.")
+            return None
+        if isinstance(sequence, str):
+            return self.seq_idxs.get(sequence, missing)
+        if isinstance(sequence, tuple):
+            assert len(sequence) == self.seq_len, "Tuple not valid length for dataset."
+            hits = np.where(np.all(np.asarray(sequence) == self.tokenized, axis=1))[0]
+            assert len(hits) > 0, "Not a valid tuple representation of a protein in this dataset."
+            return int(hits[0]) if len(hits) == 1 else int(hits)
+        raise ValueError("Input format not understood.")
+
+    # ------------------------------------------------------------------ ingest / tokenisation
+    @staticmethod
+    def csvDataLoader(csvfile, seqs_col, columns="all", index_col=None):
+        data = pd.read_csv(csvfile, index_col=index_col)
+        if columns == "all":
+            columns = [c for c in data.keys() if c != seqs_col]
+        wanted = [seqs_col] + list(columns)
+        if "Neighbours" in data:
+            wanted.append("Neighbours")
+        return data[wanted]
+
+    def tokenize(self, sequences):
+        """
+        Strings -> (N, Lmax) int tokens: letter j of `amino_acids` -> j+1, padding / unknown -> 0
+        (reference :454-474).  One table lookup over the fixed-width byte view instead of one
+        masked pass per letter.
+        """
+        arr = np.array(sequences, dtype="bytes").reshape(-1)
+        width = max(arr.dtype.itemsize, 1)
+        table = np.zeros(256, dtype=int)
+        for ch, tok in self.tokens.items():
+            if len(ch) == 1:
+                table[ch[0]] = tok
+        raw = np.frombuffer(arr.tobytes(), dtype=np.uint8).reshape(len(arr), width) if len(arr) else \
+            np.zeros((0, width), dtype=np.uint8)
+        return table[raw]
+
+    def custom_tokenize(self, seq, tokenizer=None):
+        if tokenizer is None:
+            return np.array([self.tokens[aa.encode("utf-8")] for aa in seq])
+        return "This feature is not ready yet"
+
+    def embedding(self, embedded, name):
+        self.graph[f"{name}_embedded"] = embedded
+
+    def boolean_mutant_array(self, seq=None):
+        return self.tokenized != self.tokenized[self.query(seq)]
+
+    def calc_mutated_positions(self):
+        varies = ~np.all(self.tokenized == self.tokenize(self.seed.Sequence), axis=0)
+        return np.nonzero(varies[: len(self.seed)])[0]
+
+    def coloured_seed_string(self):
+        try:
+            from colorama import Fore, Style
+            on, off = Fore.GREEN, Style.RESET_ALL
+        except ImportError:
+            on = off = ""
+        marked = set(int(i) for i in self.mutated_positions)
+        return "".join(f"{on}{c}{off}" if i in marked else c for i, c in enumerate(self.seed.Sequence))
+
+    def gen_mutation_arrays(self):
+        n_aa = len(self.amino_acids)
+        xs = np.arange(self.seq_len * n_aa)
+        ys = np.repeat(np.arange(self.seq_len), n_aa)
+        modifiers = np.tile(np.arange(n_aa), self.seq_len)
+        return xs, ys, modifiers
+
+    def generate_mutations(self, seq):
+        seq = self.tokenized[self.query(seq)]
+        xs, ys, mutations = self.mutation_arrays
+        variants = np.tile(np.asarray(seq, dtype=float), (len(xs), 1))
+        variants[xs, ys] = mutations
+        return variants[~np.all(variants == seq, axis=1)]
+
+    def get_mutated_positions(self, positions):
+        for pos in positions:
+            assert pos in self.mutated_positions, "{} is not a position that was mutated in this dataset".format(pos)
+        constants = np.setdiff1d(self.mutated_positions, positions)
+        return np.all(~self.sequence_mutation_locations[:, constants], axis=1)
+
+    def get_data(self, tokenized=False):
+        if tokenized:
+            return np.array([x[["Sequence", "Fitness"]] for x in self.graph])
+        return copy.copy(self.tokenized)
+
+    # ------------------------------------------------------------------ device residency
+    def _byte_planes(self, representation="Tokenized", idxs=None):
+        """Plane layout of a byte-token representation on the GPU (cached for the full matrix)."""
+        key = representation
+        if idxs is None and key in self._planes:
+            return self._planes[key]
+        if representation == "Tokenized":
+            mat = self.tokenized
+        else:
+            mat = np.vstack(self(representation))
+        if not np.issubdtype(np.asarray(mat).dtype, np.integer):
+            raise ValueError("not an integer representation")
+        planes = _native.pack(torch.from_numpy(np.ascontiguousarray(mat)), rows=idxs)
+        if representation == "Tokenized":
+            _native.refine_alpha(planes, len(self.amino_acids))
+        if idxs is None:
+            self._planes[key] = planes
+        return planes
+
+    def _distance_histogram(self, reference_seq):
+        planes = self._byte_planes()
+        _, hist, _ = _native.index_flags(planes, int(self.query(reference_seq)), want_dist_out=False, want_flags=False)
+        return hist.cpu().numpy()
+
+    # ------------------------------------------------------------------ indexing
+    def positions(self, positions):
+        return self.indexing(positions=positions)
+
+    def distances(self, distances):
+        return self.indexing(distances=distances)
+
+    def indexing(self, reference_seq=None, distances=None, positions=None, percentage=None, Bool="or",
+                 complement=False):
+        """
+        Distance-k / mutated-position index queries (reference :254-343), evaluated in one fused
+        1xN HIP pass: Hamming distance of every sequence to the reference row, membership of that
+        distance in `distances`, the position logic, then a device stream compaction to the
+        ascending index array.  `percentage` / `complement` are the reference's numpy post-steps.
+        """
+        assert Bool == "or" or Bool == "and", "Not a valid boolean value."
+        if reference_seq is None:
+            reference_seq = self.seed.Sequence
+        ref = int(self.query(reference_seq))
+        planes = self._byte_planes()
+
+        want = None
+        if distances is not None:
+            if type(distances) == int:
+                distances = [distances]
+            assert type(distances) == list, "Distances must be provided as integer or list"
+            _, hist, _ = _native.index_flags(planes, ref, want_dist_out=False, want_flags=False)
+            hist = hist.cpu().numpy()
+            for d in distances:
+                assert isinstance(d, (int, np.integer)) and 0 <= d < 256 and hist[d] > 0, f"{d} is not a valid distance"
+            want = distances
+
+        pos_mode, pos_mask, not_mask = 0, None, None
+        if positions is not None:
+            ref_len = len(self[reference_seq]["Sequence"])
+            width = planes.q * 16
+            pos_mask = np.zeros(width, dtype=np.uint8)
+            not_mask = np.zeros(width, dtype=np.uint8)
+            for p in positions:
+                if not -self.tokenized.shape[1] <= p < self.tokenized.shape[1]:
+                    raise IndexError(f"index {p} is out of bounds for axis 1 with size {self.tokenized.shape[1]}")
+                pos_mask[p % self.tokenized.shape[1]] = 0xFF
+            for p in range(ref_len):
+                if p not in positions:
+                    not_mask[p] = 0xFF
+            if len(positions) == 0:
+                raise TypeError("reduce() of empty sequence with no initial value")
+            pos_mode = 1 if Bool == "or" else 2
+
+        if want is None and pos_mode == 0:
+            idxs = np.array(range(len(self)))
+        else:
+            _, _, flags = _native.index_flags(planes, ref, want=want, pos_mode=pos_mode, pos_mask=pos_mask,
+                                              not_mask=not_mask, want_dist_out=False, want_hist=False)
+            idxs = _native.compact_flags(flags).cpu().numpy()
+
+        if percentage is not None:
+            assert 0 <= percentage <= 1, "Percentage must be between 0 and 1"
+            keep = np.zeros(len(idxs), dtype=bool)
+            keep[np.random.choice(np.arange(len(idxs)), size=int(len(idxs) * percentage), replace=False)] = 1
+            return idxs[keep]
+
+        assert len(idxs) != 0, "No possible valid indices have been provided."
+        if complement:
+            return idxs, np.setdiff1d(np.arange(self.len), idxs)
+        return idxs
+
+    def calc_neighbours(self, seq, eps=1, distance=hamming, comp=operator.eq, weights=False):
+        """Column indices with comp(distance to `seq`, eps) (reference :526-544)."""
+        if distance is hamming and comp in _CMP_CODE:
+            want = [d for d in range(256) if comp(d, eps)]
+            _, _, flags = _native.index_flags(self._byte_planes(), int(self.query(seq)), want=want,
+                                              want_dist_out=False, want_hist=False)
+            return _native.compact_flags(flags).cpu().numpy()
+        d = distance(self.tokenized, self.tokenized[self.query(seq)].reshape(1, -1))
+        return np.where(comp(d, eps))[1]
+
+    def neighbourhood(self, seq, eps, distance=hamming):
+        """All rows within `eps` of `seq`, the row itself included (reference :571-588)."""
+        dist, _, _ = _native.index_flags(self._byte_planes(), int(self.query(seq)), want_hist=False, want_flags=False)
+        return self[(dist <= eps).cpu().numpy().flatten()]
+
+    def neighbourhood_clustering(self, eps, distance=hamming):
+        clusters, seen = {}, set()
+        for i, seq in enumerate(self("Sequence")):
+            if i not in seen:
+                members = self.neighbourhood(seq, eps, distance)
+                clusters[i] = members
+                seen |= set(members.index)
+        return clusters
+
+    @staticmethod
+    def get_every_n(a, n=2):
+        for start in range(0, a.shape[0], n):
+            yield a[start:start + n]
+
+    @staticmethod
+    def prod_neighbours(index, out, batch_size, weights=None):
+        """COO of one batch -> {row: (cols, weights)} (reference :626-654); only the generic path needs it."""
+        row, col = out
+        row = row + index * batch_size
+        if weights is None:
+            weights = np.ones(col.shape)
+        result = {}
+        if len(row):
+            cuts = np.nonzero(np.diff(row))[0] + 1          # rows arrive grouped and ascending from where()
+            for r, c, w in zip(row[np.r_[0, cuts]], np.split(col, cuts), np.split(weights, cuts)):
+                result[r] = (c, w)
+        return result
+
+    # ------------------------------------------------------------------ graph construction
+    def build_graph(self, idxs=None, batch_size=8, eps=None, k=None, weighted=False, similarity=False,
+                    representation="Tokenized", distance=hamming, comp=operator.le, output="tuples", cap=256,
+                    _keep=None):
+        """
+        epsilon-neighbourhood (`eps`) or kNN (`k`) graph over all pairwise distances
+        (reference :656-765).  Returns the reference's list of N `(indices, weights)` tuples;
+        `output="csr"` returns the device-resident `CSRGraph` / `KNNGraph` instead (no per-row
+        Python objects — what large N wants).  `batch_size` is accepted for compatibility: the
+        HIP path tiles the pair space itself.  `cap` = slot capacity per row of the fused pass
+        (rows with more matches are recomputed exactly, so it only affects speed).
+        """
+        if operator.xor(bool(eps), bool(k)) is False:
+            raise ValueError("Epsilon or K must be provided, but both cannot be as they are different methods of graph construction.")
+        if k is not None and not isinstance(k, int):
+            raise TypeError("K must be provided as an integer.")
+
+        native = distance is hamming and (comp in _CMP_CODE) and (k is None or k <= _native.MAX_K)
+        planes = None
+        if native:
+            try:
+                planes = self._byte_planes(representation, idxs)
+            except (ValueError, TypeError):
+                native = False                      # not byte tokens / L > 128: generic torch path
+        if native and k and planes.n > _native.MAX_N_KNN:
+            native = False
+        if not native:
+            return self._build_graph_generic(idxs, batch_size, eps, k, similarity, representation, distance, comp)
+
+        if eps:
+            # similarity: comp(1/(1+eps), 1/(1+d)) & (s < 1) is the mirrored integer test on d
+            # (:720-721, :734); both sides are the same correctly rounded float32 quotient when d == eps
+            indptr, indices, wts = _native.eps_graph(planes, planes, _CMP_CODE[comp], eps, cap=cap)
+            g = CSRGraph(indptr, indices, wts, planes.n, similarity=similarity)
+        else:
+            idx, dist = _native.knn_graph(planes, planes, k)
+            g = KNNGraph(idx, dist, planes.n, similarity=similarity)
+        if _keep is not None and idxs is None:
+            self.csr_graphs[_keep] = g
+        return g if output == "csr" else g.to_tuples()
+
+    def _build_graph_generic(self, idxs, batch_size, eps, k, similarity, representation, distance, comp):
+        """
+        The distance-operator protocol for everything outside the byte-token Hamming path:
+        any callable `distance(X, Y, similarity=...) -> (M,N)` (README.md:48 of the reference).
+        Same batch loop and fp16 staging as the reference (:726-764), on the GPU, with a stable
+        sort for the canonical tie order.
+        """
+        if similarity and eps:
+            eps = 1 / (1 + eps)
+        dev = _native.device()
+        X = torch.as_tensor(np.vstack(self(representation)), dtype=torch.float16, device=dev)
+        if idxs is not None:
+            X = X[idxs, :]
+        weights, edges = [], []
+        if eps:
+            for batch in self.get_every_n(X, n=batch_size):
+                d = distance(X, batch, similarity=similarity)
+                loc = torch.where(comp(eps, d) & (d < 1)) if similarity else torch.where(comp(d, eps) & (d > 0))
+                weights.append(d[loc].cpu().numpy())
+                edges.append([x.cpu().numpy() for x in loc])
+            merged = {}
+            for i, coo in enumerate(edges):
+                merged.update(self.prod_neighbours(i, coo, batch_size, weights=weights[i]))
+            empty = (np.array([], dtype=int), np.array([], dtype=int))
+            return [merged.get(i, empty) for i in range(len(X))]
+        for batch in self.get_every_n(X, n=batch_size):
+            s = torch.sort(distance(X, batch, similarity=similarity), dim=1, descending=bool(similarity), stable=True)
+            weights.append([x.cpu().numpy() for x in s[0][:, 1:k + 1]])
+            edges.append([x.cpu().numpy() for x in s[1][:, 1:k + 1]])
+        return list(zip(flatten(edges), flatten(weights)))
+
+    # ------------------------------------------------------------------ consumers of the graph column
+    def _column_csr(self, graph):
+        """(indptr, indices, weights) numpy arrays of a Neighbours-style column."""
+        col = self(graph)
+        counts = np.fromiter((len(e[0]) for e in col), dtype=np.int64, count=len(col))
+        indptr = np.concatenate([[0], np.cumsum(counts)])
+        if indptr[-1] == 0:
+            return indptr, np.zeros(0, dtype=int), np.zeros(0)
+        return indptr, np.concatenate([e[0] for e in col]), np.concatenate([e[1] for e in col])
+
+    def degree(self, graph="Neighbours", boolean_weights=False):
+        indptr, _, w = self._column_csr(graph)
+        if boolean_weights:
+            return np.diff(indptr).astype(np.float32)
+        deg = np.zeros(len(self), dtype=np.float32)
+        rows = np.repeat(np.arange(len(self)), np.diff(indptr))
+        np.add.at(deg, rows, w.astype(np.float32))
+        return deg
+
+    def get_neighbour_coords(self, graph="Neighbours", boolean_weights=False):
+        indptr, J, w = self._column_csr(graph)
+        I = np.repeat(np.arange(len(self), dtype=int), np.diff(indptr))
+        if boolean_weights:
+            return I, J, np.ones(I.shape)
+        return I, J, w.astype(np.float32)
+
+    def adjacency(self, graph="Neighbours", boolean_weights=False):
+        from scipy import sparse
+        I, J, V = self.get_neighbour_coords(graph=graph, boolean_weights=boolean_weights)
+        return sparse.coo_matrix((V, (I, J)), shape=(len(self), len(self)))
+
+    def laplacian(self, graph="Neighbours", boolean_weights=False, mode="outdegree"):
+        L = (-1) * self.adjacency(graph, boolean_weights)
+        if mode == "outdegree":
+            D = self.degree(graph, boolean_weights)
+        elif mode == "indegree":
+            D = (-1) * np.array(L.sum(0)).reshape(-1,)
+        else:
+            raise ValueError("Not a valid degree mode.")
+        L.setdiag(D)
+        return L
+
+    def dirichlet(self, graph="Neighbours", boolean_weights=False, scaler=_DEFAULT_SCALER, mode="outdegree"):
+        if scaler is _DEFAULT_SCALER:
+            from sklearn.preprocessing import MinMaxScaler as scaler
+        fitness = self("Fitness").to_numpy().reshape(-1, 1)
+        if scaler is not None:
+            fitness = scaler().fit_transform(fitness)
+        L = self.laplacian(graph=graph, boolean_weights=boolean_weights, mode=mode)
+        return fitness.T @ L @ fitness
+
+    def local_variance(self, graph="Neighbours", boolean_weights=False, scaler=_DEFAULT_SCALER):
+        if scaler is _DEFAULT_SCALER:
+            from sklearn.preprocessing import MinMaxScaler as scaler
+        f = scaler().fit_transform(self("Fitness").to_numpy().reshape(-1, 1)).reshape(-1)
+        indptr, J, _ = self._column_csr(graph)
+        out = np.full(len(self), np.nan)
+        rows = np.repeat(np.arange(len(self)), np.diff(indptr))
+        sums = np.zeros(len(self))
+        np.add.at(sums, rows, f[rows] - f[J])
+        has = np.diff(indptr) > 0
+        out[has] = sums[has] / np.diff(indptr)[has]
+        return out
+
+    def graph_to_networkx(self, graph="Neighbours", labels=None, update_self=False, iterable="Sequence"):
+        import networkx as nx
+        names = list(self(iterable))
+        label_cols = [self(l) for l in labels] if labels is not None else []
+        g = nx.Graph()
+        for i, name in enumerate(names):
+            g.add_node(name, **{labels[j]: label_cols[j][i] for j in range(len(label_cols))})
+        for i, (nbrs, _) in enumerate(self(graph)):
+            g.add_edges_from((names[i], names[j]) for j in nbrs)
+        if update_self:
+            self.networkx_graph = g
+            return None
+        return g
+
+    # ------------------------------------------------------------------ data access for ML frameworks
+    def _resolve_idxs(self, idxs, distance, positions):
+        """README.md:36-40 of the reference documents `distance=` / `positions=` on the data
+        accessors but never wires them; here they are forwarded to `indexing`."""
+        if idxs is None and (distance not in (None, False) or positions is not None):
+            idxs = self.indexing(distances=None if distance in (None, False) else distance, positions=positions)
+        return idxs
+
+    def _xy(self, representation, labels, idxs):
+        reps = self(representation)
+        if idxs is not None:
+            X = np.vstack(reps[idxs])
+            y = np.vstack([self(l)[idxs] for l in labels]).T
+        else:
+            X = np.vstack(reps)
+            y = np.vstack([self(l) for l in labels]).T
+        return X, y
+
+    def sklearn_data(self, data=None, idxs=None, representation="Tokenized", labels=["Fitness"],
+                     split=[0.8, 0, 0.2], scaler=False, shuffle=True, random_state=0, distance=None, positions=None):
+        import sklearn.utils as skutils
+        if isinstance(split, int):
+            split = [split, 0, 1 - split]
+        assert sum(split) <= 1, "The sum of the split terms must be between 0 and 1"
+        idxs = self._resolve_idxs(idxs, distance, positions)
+        tokenized, labels = self._xy(representation, labels, idxs)
+        if shuffle:
+            tokenized, labels = skutils.shuffle(tokenized, labels, random_state=random_state)
+        if scaler:
+            labels = scaler.fit_transform(labels.reshape(-1, 1)).reshape(-1)
+        labels = labels.ravel()
+        a, b = int(len(tokenized) * split[0]), int(len(tokenized) * sum(split[:2]))
+        parts = [tokenized[:a], labels[:a], tokenized[a:b], labels[a:b], tokenized[b:], labels[b:]]
+        return tuple(p.astype("float") for p in parts)
+
+    def gen_dataloaders(self, labels, keys, params, split_points):
+        a, b = split_points
+        out = {}
+        for name, part in (("train", keys[:a]), ("val", keys[a:b]), ("test", keys[b:])):
+            if len(part):
+                out[name] = torch.utils.data.DataLoader(Dataset(part, labels), **params)
+        return out
+
+    def pytorch_dataloaders(self, split=[0.8, 0, 0.2], idxs=None, representation="Tokenized", labels=["Fitness"],
+                            distance=False, positions=None,
+                            params={"batch_size": 500, "shuffle": True, "num_workers": 8},
+                            unsupervised=False, real_label=0):
+        idxs = self._resolve_idxs(idxs, distance, positions)
+        tokenized, labels = self._xy(representation, labels, idxs)
+        keys = [torch.Tensor(t.astype("float32")).long() for t in tokenized]
+        if unsupervised:
+            data_labels = {key: real_label for key in keys}
+        else:
+            data_labels = {key: lab for key, lab in zip(keys, labels)}
+        cuts = [int(len(tokenized) * split[0]), int(len(tokenized) * sum(split[:2]))]
+        return self.gen_dataloaders(labels=data_labels, keys=list(data_labels.keys()), params=params, split_points=cuts)
+
+    def fit(self, model, model_args, save_model=False, **kwargs):
+        x_train, y_train, _, _, x_test, y_test = self("sklearn", **kwargs)
+        model = model(**model_args)
+        if model.__class__.__name__ == "NeuralNetRegressor":
+            y_train, y_test = y_train.reshape(-1, 1), y_test.reshape(-1, 1)
+        print(f"Training model {model}")
+        model.fit(x_train, y_train)
+        train_score = model.score(x_train, y_train)
+        print(f"Model score on training data: {train_score}")
+        test_score = model.score(x_test, y_test)
+        print(f"Score of {model} on testing data is {test_score}")
+        if save_model:
+            self.learners[f"{model}"] = model
+        return train_score, test_score

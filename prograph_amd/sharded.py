@@ -1,0 +1,91 @@
+"""
+Row-block sharding of the N x N pair space over the GPUs of one node.
+
+The reference has no multi-GPU code; its only parallel structure is that every batch of rows
+is independent (prograph/prograph.py:731-732, :756-760).  That independence is the shard
+boundary here: one process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI),
+rank r owns a contiguous block of rows, ONE all-gather of the byte-token shards up front
+gives every GPU the full (N, L) matrix (64 MB at N = 1M, L = 64), and after that no rank
+talks to another: each computes `rows_local x N` pairs and keeps its CSR / kNN slice with
+GLOBAL column indices.  Concatenating the slices in rank order is the single-GPU result.
+
+Everything here is host logic + `torch.distributed` plumbing; the compute entry points are the
+same C-ABI calls as the single-GPU path (prograph_amd/_native.py).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native
+from .graph import CSRGraph, KNNGraph
+
+
+def row_block(n, world, rank):
+    """Contiguous block of rank `rank`: [r*ceil(n/world), min(n, (r+1)*ceil(n/world)))."""
+    per = -(-int(n) // int(world))
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def shard_rows(n, world):
+    return [row_block(n, world, r) for r in range(world)]
+
+
+def allgather_tokens(local_tokens, n_total, group=None):
+    """
+    Gather the (rows_r, L) uint8 shards of all ranks into the full (n_total, L) matrix on every
+    rank with one `all_gather_into_tensor` (the last rank's block may be short: shards are
+    zero-padded to ceil(n/world) rows for the collective and the tail is dropped afterwards).
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_tokens[:n_total]
+    per = -(-int(n_total) // world)
+    L = local_tokens.shape[1]
+    if local_tokens.shape[0] != per:
+        padded = torch.zeros((per, L), dtype=local_tokens.dtype, device=local_tokens.device)
+        padded[: local_tokens.shape[0]] = local_tokens
+        local_tokens = padded
+    full = torch.empty((per * world, L), dtype=local_tokens.dtype, device=local_tokens.device)
+    dist.all_gather_into_tensor(full, local_tokens.contiguous(), group=group)
+    return full[:n_total]
+
+
+def build_graph_sharded(local_tokens, n_total, eps=None, k=None, comp_code=_native.CMP_LE, cap=256,
+                        max_token=None, group=None):
+    """
+    This rank's slice of the epsilon / kNN graph of the full matrix.
+      local_tokens  (rows_r, L) uint8 tensor on this rank's GPU: rows row_block(n_total, world, rank)
+    Returns CSRGraph / KNNGraph with `row0` = first global row of the slice.
+    """
+    if bool(eps) == bool(k):
+        raise ValueError("Epsilon or K must be provided, but both cannot be as they are different methods of graph construction.")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = row_block(n_total, world, rank)
+    full = allgather_tokens(local_tokens, n_total, group=group)
+    planes = _native.pack(full)
+    if max_token is not None:
+        _native.refine_alpha(planes, max_token)
+    if hi <= lo:
+        return None
+    if eps:
+        indptr, indices, wts = _native.eps_graph(planes, planes, comp_code, eps, row0=lo, nrows=hi - lo, cap=cap)
+        return CSRGraph(indptr, indices, wts, n_total, row0=lo)
+    idx, d = _native.knn_graph(planes, planes, k, row0=lo, nrows=hi - lo)
+    return KNNGraph(idx, d, n_total, row0=lo)
+
+
+def gather_csr_to_host(graph, group=None):
+    """Optional: concatenate every rank's CSR slice on rank 0 (host side, object gather)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    part = None if graph is None else graph.host()
+    if world == 1:
+        return part
+    parts = [None] * world
+    dist.all_gather_object(parts, part, group=group)
+    parts = [p for p in parts if p is not None]
+    indptr = [parts[0][0]]
+    for p in parts[1:]:
+        indptr.append(p[0][1:] + indptr[-1][-1])
+    return np.concatenate(indptr), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])

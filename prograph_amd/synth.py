@@ -42,16 +42,19 @@ def h(seed, stream, i):
         return mix64(np.uint64(seed) + _GOLD * (np.uint64(4) * i + np.uint64(stream + 1)))
 
 
-def clustered_tokens(N, L, seed=DEFAULT_SEED, members=256):
-    """(N, L) uint8 tokens in 1..20, clustered as described in the module docstring."""
+def clustered_tokens(N, L, seed=DEFAULT_SEED, members=256, row0=0, nrows=None):
+    """(N, L) uint8 tokens in 1..20, clustered as described in the module docstring.
+    `row0`/`nrows` return only rows [row0, row0+nrows) of the same N-row matrix (every row is a
+    pure function of its index, so ranks can generate their own shard)."""
     N, L = int(N), int(L)
+    nrows = N - row0 if nrows is None else int(nrows)
     n_centres = max(1, N // members)
     cj = np.arange(n_centres * L, dtype=np.uint64)
     centres = (1 + h(seed, 0, cj) % np.uint64(20)).astype(np.uint8).reshape(n_centres, L)
-    i = np.arange(N, dtype=np.uint64)
+    i = np.arange(row0, row0 + nrows, dtype=np.uint64)
     tok = centres[(i % np.uint64(n_centres)).astype(np.int64)].copy()
     m = (1 + h(seed, 1, i) % np.uint64(3)).astype(np.int64)
-    rows = np.arange(N)
+    rows = np.arange(nrows)
     for t in range(3):
         act = m > t
         pos = (h(seed, 2, np.uint64(8) * i + np.uint64(t)) % np.uint64(L)).astype(np.int64)

@@ -160,3 +160,34 @@ def test_levenshtein_definition():
         for band in (1, 3, 8):
             got = O.levenshtein_banded(a, la, b, lb, band)
             assert got == min(full, band + 1) if full <= band else got == band + 1
+
+
+def test_c_oracle_matches_python_oracle():
+    """The C leg (oracle/oracle.c) is pinned to the Python oracle, which is pinned to the reference."""
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    for name in SETS:
+        g = load_golden(name)
+        tok = g["tokens"]
+        for key in g.files:
+            if key.endswith("_indptr") and "sub" not in key:
+                e = int(key[3:-7])
+                ip, ix, w = C.eps_csr(tok, 0, e)
+                assert np.array_equal(ip, g[f"eps{e}_indptr"]) and np.array_equal(ix, g[f"eps{e}_indices"])
+                assert np.array_equal(w, g[f"eps{e}_weights"])
+            if key.startswith("knn") and key.endswith("_idx") and "sub" not in key:
+                k = int(key[3:-4])
+                ix, d = C.knn(tok, k)
+                assert np.array_equal(ix, g[f"knn{k}_idx"]) and np.array_equal(d, g[f"knn{k}_w"])
+    g = load_golden("ref_synthetic_csv")
+    for nm, code in [("eq", 2), ("lt", 1), ("ge", 3), ("gt", 4)]:
+        ip, ix, w = C.eps_csr(g["tokens"], code, 2)
+        assert np.array_equal(ip, g[f"eps2_{nm}_indptr"]) and np.array_equal(ix, g[f"eps2_{nm}_indices"])
+    k = load_golden("hamming_kats")
+    assert np.array_equal(C.hamming(k["r0_X"], k["r0_Y"]), k["r0_out"])
+    assert np.array_equal(C.hamming(k["wide_X"], k["wide_Y"]), k["wide_out"])
+    # generator: Python and C restatements agree bit for bit
+    for (n, l, seed, mem) in [(1000, 32, 20260104, 256), (777, 20, 5, 64), (300, 64, 99, 256)]:
+        assert np.array_equal(C.synth(n, l, seed, mem), synth.clustered_tokens(n, l, seed=seed, members=mem))
+    ip, ix, w = C.eps_csr(g["tokens"], 0, 1, row0=100, nrows=50)
+    assert np.array_equal(ip, g["eps1_indptr"][100:151] - g["eps1_indptr"][100])

@@ -1,0 +1,301 @@
+"""
+The reference's own test-suite (tests/tests.py of acmater/prograph, 50 methods) restated
+against `prograph_amd.Prograph`, plus golden-vector checks of the drop-in surface.
+
+Every test runs twice:
+  * backend "hip"  (marked gpu): the real HIP kernels through the C ABI;
+  * backend "fake" (CPU):        tests/fake_native.py answers the native calls with the oracle,
+                                 so only the HOST logic is under test there.
+The input file is `data/synthetic_data.csv` of the reference, rebuilt from the committed
+golden vector (tokens + fitness) because /root/reference does not exist on the GPU box.
+"""
+import operator
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import load_golden
+from prograph_amd import synth
+
+NW0 = {"batch_size": 500, "shuffle": True, "num_workers": 0}
+
+
+@pytest.fixture(params=[pytest.param("fake"), pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request, monkeypatch):
+    if request.param == "fake":
+        import fake_native
+        fake_native.install(monkeypatch)
+    else:
+        from prograph_amd import _native
+        _native.lib(); _native.device()
+    return request.param
+
+
+@pytest.fixture
+def csv_path(tmp_path):
+    g = load_golden("ref_synthetic_csv")
+    p = tmp_path / "data"
+    p.mkdir()
+    f = p / "synthetic_data.csv"
+    pd.DataFrame({"Sequence": synth.tokens_to_strings(g["tokens"]), "Fitness": g["fitness"]}).to_csv(f)
+    return str(f)
+
+
+@pytest.fixture
+def pgraph(backend, csv_path, capsys):
+    from prograph_amd import Prograph
+    pg = Prograph(file=csv_path)
+    out = capsys.readouterr().out
+    assert "Number of Sequences : 1000" in out and "Max Distance        : 3" in out
+    assert "Number of Distances : 4" in out and "Longest Sequence    : 3" in out
+    return pg
+
+
+# ---------------------------------------------------------------- tests/tests.py:15-23, 104-114
+def test_gen_pgraph_errors(backend):
+    from prograph_amd import Prograph
+    with pytest.raises(TypeError):
+        Prograph()
+    with pytest.raises(FileNotFoundError):
+        Prograph(file="None.pkl")
+    with pytest.raises(FileNotFoundError):
+        Prograph(file=2)
+    with pytest.raises(FileNotFoundError):
+        Prograph(file=None)
+
+
+# ---------------------------------------------------------------- tests/tests.py:27-39
+def test_query_forms(pgraph):
+    assert pgraph["AAC"]["Sequence"] == "AAC"
+    assert pgraph("Sequence")[26] == "ADH"
+    assert pgraph[(1, 2, 2)]["Sequence"] == "ACC"
+    assert len(pgraph) == 1000
+    assert pgraph[[1, 2, 4]]["Sequence"][2] == "AAD"
+    assert pgraph[np.array([63, 87])]["Sequence"][87] == "AKI"
+    with pytest.raises(KeyError):
+        pgraph.label_iter("PLK")                                   # tests/tests.py:87-90
+
+
+# ---------------------------------------------------------------- tests/tests.py:41-53, 92-98
+def test_indexing_known_answers(pgraph):
+    g = load_golden("ref_synthetic_csv")
+    assert len(pgraph.indexing(positions=[1, 2])) == 99
+    assert len(pgraph.indexing(distances=3)) == 729
+    assert len(pgraph.indexing(positions=[1, 2], distances=2)) == 81 and len(pgraph.indexing(distances=2)) == 243
+    assert len(pgraph.indexing(percentage=0.7)) == 700
+    assert len(pgraph.indexing(positions=[1, 2], distances=2, percentage=0.3)) == 24
+    assert pgraph.indexing(positions=[1, 2], distances=2, complement=True)[1][12] == 30
+    with pytest.raises(AssertionError):
+        pgraph.indexing(distances=[1, 2, 4])
+    assert len(pgraph.indexing(distances=[1, 3])) == 756
+    assert pgraph[pgraph.indexing(reference_seq="LDC", positions=[1])]["Sequence"][901] == "LAC"
+    # bit-exact against the reference's outputs
+    for key, kw in [("ix_pos12", dict(positions=[1, 2])), ("ix_pos12_and", dict(positions=[1, 2], Bool="and")),
+                    ("ix_d3", dict(distances=3)), ("ix_d2", dict(distances=2)), ("ix_d13", dict(distances=[1, 3])),
+                    ("ix_pos12_d2", dict(positions=[1, 2], distances=2)),
+                    ("ix_LDC_pos1", dict(reference_seq="LDC", positions=[1])),
+                    ("ix_LDC_d1", dict(reference_seq="LDC", distances=1))]:
+        got = pgraph.indexing(**kw)
+        assert got.dtype == np.int64 and np.array_equal(got, g[key]), key
+    a, b = pgraph.indexing(positions=[1, 2], distances=2, complement=True)
+    assert np.array_equal(a, g["ix_pos12_d2_c0"]) and np.array_equal(b, g["ix_pos12_d2_c1"])
+    assert np.array_equal(pgraph.positions([1, 2]), g["ix_pos12"]) and np.array_equal(pgraph.distances(3), g["ix_d3"])
+    with pytest.raises(AssertionError):
+        pgraph.indexing(Bool="xor")
+    with pytest.raises(AssertionError):
+        pgraph.indexing(distances="3")
+    with pytest.raises(AssertionError):
+        pgraph.indexing(percentage=1.5)
+    assert np.array_equal(pgraph.indexing(), np.arange(1000))
+
+
+# ---------------------------------------------------------------- tests/tests.py:63-64
+def test_calc_neighbours(pgraph):
+    g = load_golden("ref_synthetic_csv")
+    assert np.all(pgraph.calc_neighbours(seq="ACL") == pgraph["ACL"]["Neighbours"][0])
+    assert np.array_equal(pgraph.calc_neighbours(seq="ACL"), g["calc_neigh_ACL"])
+    assert np.array_equal(pgraph.calc_neighbours(seq="ACL", eps=2, comp=operator.le), g["calc_neigh_ACL_le2"])
+    nb = pgraph.neighbourhood("ACL", 1)
+    assert len(nb) == 28 and "ACL" in set(nb["Sequence"])
+
+
+# ---------------------------------------------------------------- tests/tests.py:66-85
+def test_pytorch_dataloaders(pgraph):
+    train, test = pgraph.pytorch_dataloaders(params=NW0).values()
+    assert len(next(iter(test))[0]) == 200
+    train, test = pgraph.pytorch_dataloaders(idxs=np.arange(10), params=NW0).values()
+    assert len(next(iter(test))[0]) == 2
+    train, test = pgraph.pytorch_dataloaders(idxs=pgraph.indexing(distances=1), params=NW0).values()
+    assert len(next(iter(test))[0]) == 6
+    train, test = pgraph.pytorch_dataloaders(idxs=pgraph.indexing(distances=[1, 2]), params=NW0).values()
+    assert len(next(iter(test))[0]) == 54
+    train, test = pgraph.pytorch_dataloaders(idxs=pgraph.indexing(positions=[1, 2]), params=NW0).values()
+    assert len(next(iter(test))[0]) == 20
+    train, test = pgraph.pytorch_dataloaders(unsupervised=True, params=NW0).values()
+    batch = next(iter(test))
+    assert torch.all(0 == batch[1]) and len(batch[1]) == 200
+    # README.md:36-40 of the reference: distance= / positions= on the accessors
+    train, test = pgraph("pytorch", positions=[1, 2], params=NW0).values()
+    assert len(next(iter(test))[0]) == 20
+    xtr, ytr, _, _, xte, yte = pgraph("sklearn", distance=2, positions=[1, 2])
+    assert len(xtr) + len(xte) == 81 and xtr.dtype == np.float64
+    xtr, ytr, xv, yv, xte, yte = pgraph("sklearn")
+    assert (len(xtr), len(xv), len(xte)) == (800, 0, 200)
+
+
+# ---------------------------------------------------------------- tests/tests.py:100-122
+def test_networkx_and_save_roundtrip(pgraph, tmp_path, capsys):
+    from prograph_amd import Prograph
+    from prograph_amd.utils import save
+    pgraph.graph_to_networkx(labels=["Fitness", "Tokenized"], update_self=True)
+    assert "Fitness" in pgraph.networkx_graph.nodes["AAA"].keys()
+    assert save(pgraph, name="test", directory=str(tmp_path) + "/")
+    again = Prograph(file=str(tmp_path / "test.pkl"))
+    assert again[0]["Sequence"] == "AAA"
+    assert np.array_equal(again["ACL"]["Neighbours"][0], pgraph["ACL"]["Neighbours"][0])
+    assert again[0]["Fitness"] == 0.660972597708149               # tests/tests.py:108
+
+
+# ---------------------------------------------------------------- tests/tests.py:124-133
+def test_tokenization(pgraph):
+    assert np.all(pgraph.tokenize("ACA") == np.array([1, 2, 1]))
+    assert np.all(pgraph.tokenize(["ACA", "ACC"]) == np.array([[1, 2, 1], [1, 2, 2]]))
+    tokens = pgraph.tokenize(["ACCCACAAA", "ACAA"])
+    assert np.all(tokens == np.array([[1, 2, 2, 2, 1, 2, 1, 1, 1], [1, 2, 1, 1, 0, 0, 0, 0, 0]]))
+    assert len(pgraph.tokenize([])) == 0
+    from oracle import prograph_oracle as O
+    seqs = ["ACDEFGHIKLMNPQRSTVWY", "XYZ-", "", "WWWWWWWWWWWWWWWWWWWWWWWW"]
+    assert np.array_equal(pgraph.tokenize(seqs), O.tokenize(seqs)) and pgraph.tokenize(seqs).dtype == O.tokenize(seqs).dtype
+    assert np.array_equal(pgraph.tokenized, load_golden("ref_synthetic_csv")["tokens"])
+    assert pgraph.token_dict[(1, 2, 2)] == pgraph.query("ACC")
+
+
+# ---------------------------------------------------------------- tests/tests.py:135-137, 157-158
+def test_matrix_and_degree(pgraph):
+    g = load_golden("ref_synthetic_csv")
+    assert np.all(pgraph.adjacency().todense()[:3, :3] == np.array([[0, 1, 1], [1, 0, 1], [1, 1, 0]]))
+    assert np.all(pgraph.degree() == np.array([27 for _ in range(1000)]))
+    assert pgraph.degree().dtype == np.float32 and np.array_equal(pgraph.degree(), g["degree"])
+    assert np.array_equal(pgraph.degree(boolean_weights=True), g["degree"])
+    assert np.array_equal(pgraph.csr_graphs["Neighbours"].degree(), g["degree"])
+    L = pgraph.laplacian()
+    assert L.shape == (1000, 1000) and abs(L.sum()) < 1e-3
+    assert np.isfinite(pgraph.dirichlet()).all() and pgraph.local_variance().shape == (1000,)
+
+
+# ---------------------------------------------------------------- build_graph: reference outputs, bit-exact
+def _check_tuples(neigh, g, name, knn=False):
+    assert isinstance(neigh, list)
+    if knn:
+        idx = np.stack([a[0] for a in neigh]); w = np.stack([a[1] for a in neigh])
+        assert idx.dtype == np.int64 and np.array_equal(idx, g[name + "_idx"])
+        gw = g[name + "_w"]
+        assert np.array_equal(w, gw) if not np.issubdtype(gw.dtype, np.integer) else (w.dtype == np.int64 and np.array_equal(w, gw))
+        return
+    counts = np.array([len(a[0]) for a in neigh])
+    assert np.array_equal(np.concatenate([[0], np.cumsum(counts)]), g[name + "_indptr"])
+    idx = np.concatenate([a[0] for a in neigh]); w = np.concatenate([a[1] for a in neigh])
+    assert all(a[0].dtype == np.int64 for a in neigh)
+    assert np.array_equal(idx, g[name + "_indices"])
+    gw = g[name + "_weights"]
+    if np.issubdtype(gw.dtype, np.integer):
+        assert all(a[1].dtype == np.int64 for a in neigh) and np.array_equal(w, gw)
+    else:
+        assert w.dtype == gw.dtype and np.array_equal(w, gw)
+
+
+def test_build_graph_matches_reference(pgraph):
+    g = load_golden("ref_synthetic_csv")
+    _check_tuples(list(pgraph.graph["Neighbours"]), g, "eps1")
+    _check_tuples(pgraph.build_graph(eps=2), g, "eps2")
+    _check_tuples(pgraph.build_graph(eps=3, cap=8), g, "eps3")
+    for nm, op in [("eq", operator.eq), ("lt", operator.lt), ("ge", operator.ge), ("gt", operator.gt)]:
+        _check_tuples(pgraph.build_graph(eps=2, comp=op), g, "eps2_" + nm)
+    _check_tuples(pgraph.build_graph(eps=1, batch_size=5), g, "eps1_b5")
+    _check_tuples(pgraph.build_graph(eps=1, idxs=g["sub_idxs"]), g, "eps1_sub")
+    _check_tuples(pgraph.build_graph(eps=1, similarity=True), g, "eps1_sim")
+    for k in (1, 2, 16):
+        _check_tuples(pgraph.build_graph(k=k), g, f"knn{k}", knn=True)
+    _check_tuples(pgraph.build_graph(k=4, similarity=True), g, "knn4_sim", knn=True)
+    _check_tuples(pgraph.build_graph(k=3, idxs=g["sub_idxs"]), g, "knn3_sub", knn=True)
+    csr = pgraph.build_graph(eps=2, output="csr")
+    assert csr.nnz == int(g["eps2_indptr"][-1]) and csr.nrows == 1000
+
+
+def test_build_graph_argument_errors(pgraph):
+    with pytest.raises(ValueError):
+        pgraph.build_graph()
+    with pytest.raises(ValueError):
+        pgraph.build_graph(eps=1, k=1)
+    with pytest.raises(ValueError):
+        pgraph.build_graph(k=0)                                    # tests/tests.py:149-151
+    with pytest.raises(ValueError):
+        pgraph.build_graph(eps=0)
+    with pytest.raises(TypeError):
+        pgraph.build_graph(k=0.5)                                  # tests/tests.py:152-154
+
+
+# ---------------------------------------------------------------- tests/tests.py:173-191: the distance operator
+def test_hamming_operator(backend):
+    from prograph_amd.distance import hamming
+    X = torch.Tensor([[1, 2, 3], [4, 5, 6]]); Y = torch.Tensor([[1, 2, 3], [7, 8, 9]])
+    assert torch.all(hamming(X, Y) == torch.Tensor([[0, 3], [3, 3]]))
+    assert torch.all(hamming(X, torch.Tensor([1, 2, 3])) == torch.Tensor([[0, 3]]))
+    assert torch.all(hamming(torch.Tensor([4, 5, 6]), torch.Tensor([1, 2, 3])) == torch.Tensor([[3]]))
+    with pytest.raises(ValueError):
+        hamming(torch.Tensor([4, 5, 6]), torch.Tensor())
+    out = hamming(X, Y)
+    assert out.dtype == torch.int64 and out.device == X.device and tuple(out.shape) == (2, 2)
+    g = load_golden("hamming_kats")
+    for i in range(6):       # incl. unequal D (zero padding) and D > 128 (generic expression)
+        got = hamming(g[f"r{i}_X"].astype(np.int64), g[f"r{i}_Y"].astype(np.int64))
+        assert np.array_equal(got.numpy(), g[f"r{i}_out"]), i
+    assert np.array_equal(hamming(g["wide_X"], g["wide_Y"]).numpy(), g["wide_out"])
+    assert np.array_equal(hamming(g["i32_X"], g["i32_Y"]).numpy(), g["i32_out"])
+    sim = hamming(g["r0_X"].astype(np.int64), g["r0_Y"].astype(np.int64), similarity=True).numpy()
+    assert sim.dtype == g["sim_out"].dtype and np.array_equal(sim, g["sim_out"])
+    assert np.array_equal(hamming(np.array([[1.5, 2.0]]), np.array([[1.5, 3.0]])).numpy(), [[1]])
+
+
+# ---------------------------------------------------------------- the generic distance protocol (custom callables)
+def test_custom_distance_callable_and_comp(pgraph):
+    g = load_golden("ref_synthetic_csv")
+    from prograph_amd.distance import hamming
+
+    def my_distance(X, Y, similarity=False):
+        return hamming(X, Y, similarity=similarity)
+    _check_tuples(pgraph.build_graph(eps=2, distance=my_distance), g, "eps2")
+    _check_tuples(pgraph.build_graph(k=2, distance=my_distance), g, "knn2", knn=True)
+    _check_tuples(pgraph.build_graph(eps=2, comp=lambda a, b: a <= b), g, "eps2")
+    _check_tuples(pgraph.build_graph(k=64)[:5], {"knn64_idx": np.stack([a[0] for a in pgraph.build_graph(k=64, distance=my_distance)[:5]]),
+                                                 "knn64_w": np.stack([a[1] for a in pgraph.build_graph(k=64, distance=my_distance)[:5]])},
+                  "knn64", knn=True)
+
+
+@pytest.mark.parametrize("name", ["synth_n1000_l32", "synth_n515_l20_dups", "synth_n300_varlen24"])
+def test_constructor_on_synthetic_sets(backend, name, tmp_path, capsys):
+    """Prograph(csv) end to end on seeded sets incl. duplicates and variable length (zero padding)."""
+    from prograph_amd import Prograph
+    g = load_golden(name)
+    tok = g["tokens"]
+    f = tmp_path / (name + ".csv")
+    pd.DataFrame({"Sequence": synth.tokens_to_strings(tok), "Fitness": np.linspace(0, 1, len(tok))}).to_csv(f)
+    pg = Prograph(file=str(f))
+    capsys.readouterr()
+    assert np.array_equal(pg.tokenized, tok)
+    _check_tuples(list(pg.graph["Neighbours"]), g, "eps1")
+    for key in g.files:
+        if key.endswith("_indptr") and "sub" not in key and key != "eps1_indptr":
+            _check_tuples(pg.build_graph(eps=int(key[3:-7])), g, key[:-7])
+        if key.startswith("knn") and key.endswith("_idx") and "sub" not in key:
+            _check_tuples(pg.build_graph(k=int(key[3:-4])), g, key[:-4], knn=True)
+    if "sub_idxs" in g.files:
+        _check_tuples(pg.build_graph(eps=2, idxs=g["sub_idxs"]), g, "eps2_sub")
+        _check_tuples(pg.build_graph(k=3, idxs=g["sub_idxs"]), g, "knn3_sub", knn=True)
+    d = g["dist_to_ref"][0].astype(np.int64)
+    r = int(g["ref_row"])
+    want = int(np.bincount(d).argmax())
+    assert np.array_equal(pg.indexing(reference_seq=r, distances=want), np.where(d == want)[0])
