@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz: int lane-ops/s ceiling
+VALU_WAVE_INSTR = 256 * 4 * 2.4e9 / 4   # measured: one wave64 integer VALU instruction per 4 cycles per SIMD
 
 WORKLOADS = {
     "cfg2": dict(N=50_000, L=32, mode="eps", eps=2, k=None, shards=1),
@@ -133,7 +133,7 @@ def main():
 
     def step(record):
         full = tok_dev if G == 1 else sharded.allgather_tokens(shard_dev, N)
-        planes = _native.refine_alpha(_native.pack(full), 20)
+        planes = _native.pack(full, bits=5)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         if wl["mode"] == "eps":
@@ -148,7 +148,7 @@ def main():
             indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
             weights = torch.empty(max(nnz, 1), dtype=torch.uint8, device=dev)
             args = (_native._ptr(planes.buf), planes.npad, lo, rows_local, _native._ptr(planes.buf), planes.npad, planes.n,
-                    planes.q * 16, planes.alpha, _native.CMP_LE, float(wl["eps"]), cap)
+                    planes.g * 32, planes.bits, _native.CMP_LE, float(wl["eps"]), cap)
             _native._check(L_.pg_eps_compact(*args, _native._ptr(slot_idx), _native._ptr(slot_w), _native._ptr(counts),
                                              _native._ptr(indptr), _native._ptr(indices), _native._ptr(weights),
                                              _native._stream()), "compact")
@@ -186,7 +186,7 @@ def main():
         out_bytes = 5 * k * rows_local if wl["mode"] == "knn" else 8 * (rows_local + 1) + 5 * result.get("nnz", 0)
         alg_bytes = float(rows_local) * N * L + rows_local * L + out_bytes      # SURVEY.md §8-d, per launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        ops_per_pair = (7 * (L // 4) / 3.0 + 1)                                 # 5-bit counter: 7 VALU ops / 12 tokens + compare
+        ops_per_pair = 6 * ((L + 31) // 32) + 0.5                               # 5 bit planes: 6 VALU ops / 32 tokens + shared min/compare
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
@@ -209,7 +209,7 @@ def main():
                          "note": "algorithmic bytes = L per ordered pair (SURVEY.md 8-d); the operand matrix is "
                                  "cache resident so this HBM-equivalent rate is not capped at 1; the kernel is "
                                  "VALU-issue bound, see valu_frac",
-                         "valu_frac": (rows_local * N / (kern_ms * 1e-3)) * ops_per_pair / VALU_LANE_OPS},
+                         "valu_frac": (rows_local * N / 64.0 / (kern_ms * 1e-3)) * ops_per_pair / VALU_WAVE_INSTR},
         }
         if wl["mode"] == "eps":
             line["config"]["nnz"] = result.get("nnz")

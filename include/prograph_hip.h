@@ -18,12 +18,15 @@
  *     `pg_last_error()` returns a thread-local human readable message;
  *   - no exceptions cross the boundary, no hidden global state.
  *
- * Token storage: the "plane" layout.  A token matrix of N sequences x L byte tokens
- * is held as Q = ceil(L/16) planes of Npad 16-byte chunks, chunk q of sequence n at
- * byte offset (q*Npad + n)*16; bytes past L inside a sequence and sequences past N
- * are zero.  Npad = pg_npad(N) (a multiple of 256).  A 64-lane wavefront that owns 64
- * consecutive sequences therefore reads one plane chunk per lane as a single fully
- * coalesced 1 KiB `global_load_dwordx4`.
+ * Token storage: bit-sliced records in chunk-major order ("planes").  A sequence of L tokens
+ * of `bits` bits each is G = ceil(L/32) groups of `bits` bit-plane dwords: dword g*bits+p has
+ * bit j = bit p of token 32g+j (positions past L are 0).  The W = G*bits dwords of a record
+ * are split into Q = ceil(W/4) 16-byte chunks (tail dwords zero); chunk q of sequence n lives
+ * at byte offset (q*Npad + n)*16, Npad = pg_npad(N) (a multiple of 256, sequences past N are
+ * zero).  A 64-lane wavefront that owns 64 consecutive sequences therefore reads one chunk per
+ * lane as a single fully coalesced 1 KiB `global_load_dwordx4`, and the Hamming distance of
+ * two records is B+1 VALU instructions per 32 tokens (xor, v_bitop3 x (B-1), v_bcnt).
+ * Buffer size: pg_nchunks(L, bits) * pg_npad(N) * 16 bytes.
  */
 #ifndef PROGRAPH_HIP_H
 #define PROGRAPH_HIP_H
@@ -46,10 +49,9 @@ extern "C" {
 #define PG_MAX_N_KNN  16777216     /* 2^24                                               */
 #define PG_MAX_K      63           /* k+1 sorted keys live in the 64 lanes of one VGPR   */
 
-/* token alphabets: selects the nonzero-byte test of the mismatch counter */
-#define PG_ALPHA_5BIT 5            /* every token <= 31   (7 VALU ops / 12 tokens)       */
-#define PG_ALPHA_7BIT 7            /* every token <= 127  (3 VALU ops / 4 tokens)        */
-#define PG_ALPHA_8BIT 8            /* any byte            (5 VALU ops / 4 tokens)        */
+/* bit planes per token: fixed when a matrix is packed, passed to every call that reads it */
+#define PG_BITS_5 5                /* every token <= 31 (20 amino acids + pad): 6 VALU ops / 32 tokens */
+#define PG_BITS_8 8                /* any byte token 0..255:                    9 VALU ops / 32 tokens */
 
 /* comparator codes for pg_eps_*: the reference's `comp` argument (operator.le default,
  * prograph/prograph.py:665) restricted to the five orderings                      */
@@ -63,9 +65,10 @@ int         pg_version(void);
 const char *pg_last_error(void);
 int         pg_device_info(int *cu_count, int *wave_size, char *arch, int arch_len);
 
-/* Npad for N sequences (multiple of 256), Q for L bytes (ceil(L/16)). */
+/* Npad for N sequences (multiple of 256); groups of 32 positions; 16-byte chunks per record. */
 int64_t     pg_npad(int64_t n);
-int         pg_nplanes(int l);
+int         pg_ngroups(int l);
+int         pg_nchunks(int l, int bits);
 
 /*
  * pg_pack_planes — row-major tokens -> plane layout.
@@ -75,12 +78,13 @@ int         pg_nplanes(int l);
  *   src        (n, l) row-major, leading dimension `ld` ELEMENTS, element size
  *              `elem_bytes` in {1,2,4,8} (uint8 / int16 / int32 / int64 tokens)
  *   rows       optional int64[n] gather list (the reference's `idxs`), NULL = identity
- *   planes     out, Q*npad*16 bytes, fully overwritten (padding zeroed)
- *   flags      out, uint32[1], OR-ed: bit0 = some token > 127, bit1 = some token
- *              outside 0..255 (such tokens are truncated; caller must not use result)
+ *   bits       PG_BITS_5 or PG_BITS_8
+ *   planes     out, pg_nchunks(l,bits)*npad*16 bytes, fully overwritten (padding zeroed)
+ *   flags      out, uint32[1]: set to 1 when some token is outside 0..2^bits-1 (such tokens
+ *              are truncated; the caller must not use the result)
  */
 int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld,
-                   const int64_t *rows, void *planes, int64_t npad, uint32_t *flags,
+                   const int64_t *rows, int bits, void *planes, int64_t npad, uint32_t *flags,
                    void *stream);
 
 /*
@@ -91,7 +95,7 @@ int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld
  */
 int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad,
                      const void *y_planes, int64_t m, int64_t y_npad,
-                     int l, int alpha, void *out, int out_elem_bytes, int64_t ldo,
+                     int l, int bits, void *out, int out_elem_bytes, int64_t ldo,
                      void *stream);
 
 /*
@@ -107,7 +111,7 @@ int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad,
  */
 int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
                  const void *col_planes, int64_t col_npad, int64_t ncols,
-                 int l, int alpha, int cmp, double eps, int cap,
+                 int l, int bits, int cmp, double eps, int cap,
                  int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts, void *stream);
 
 /*
@@ -127,7 +131,7 @@ int pg_exclusive_scan(const uint32_t *counts, int64_t n, int64_t *indptr, void *
  */
 int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
                    const void *col_planes, int64_t col_npad, int64_t ncols,
-                   int l, int alpha, int cmp, double eps, int cap,
+                   int l, int bits, int cmp, double eps, int cap,
                    const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts,
                    const int64_t *indptr, int32_t *indices, uint8_t *weights, void *stream);
 
@@ -141,7 +145,7 @@ int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64
  */
 int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
                    const void *col_planes, int64_t col_npad, int64_t ncols,
-                   int l, int alpha, int k, int32_t *idx_out, uint8_t *dist_out,
+                   int l, int bits, int k, int32_t *idx_out, uint8_t *dist_out,
                    void *stream);
 
 /*
@@ -153,13 +157,13 @@ int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64
  *   pos_ok  = pos_mode == 0, or: (pos_mode 1 "or": some byte selected by pos_mask
  *             differs from the reference row; 2 "and": all selected bytes differ) and no
  *             byte selected by not_mask differs          (:316-325)
- * pos_mask / not_mask: uint8[Q*16] (0xFF = selected) device arrays.
+ * pos_mask / not_mask: uint32[pg_ngroups(l)] device arrays, bit j of word g selects position 32g+j.
  *   dist_out uint8[n] (may be NULL), hist uint64[256] (may be NULL; must be zeroed by
  *   the caller), flags uint8[n] (may be NULL)
  */
-int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int alpha,
+int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int bits,
                    int64_t ref, const uint32_t *want_dist, int pos_mode,
-                   const uint8_t *pos_mask, const uint8_t *not_mask,
+                   const uint32_t *pos_mask, const uint32_t *not_mask,
                    uint8_t *dist_out, uint64_t *hist, uint8_t *flags, void *stream);
 
 /*

@@ -18,13 +18,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libprograph_hip.so")
 ABI_VERSION = 1
 
-ALPHA_5BIT, ALPHA_7BIT, ALPHA_8BIT = 5, 7, 8
+BITS_5, BITS_8 = 5, 8
 CMP_LE, CMP_LT, CMP_EQ, CMP_GE, CMP_GT = 0, 1, 2, 3, 4
 MAX_L, MAX_K, MAX_N_KNN = 128, 63, 1 << 24
 
 # every symbol include/prograph_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_nplanes", "pg_pack_planes",
+    "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_pack_planes",
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
     "pg_eps_compact", "pg_knn_hamming", "pg_index_flags", "pg_compact_flags",
 ]
@@ -66,12 +66,14 @@ def _load():
         lib.pg_last_error.restype = ctypes.c_char_p
         lib.pg_npad.restype = _i64
         lib.pg_npad.argtypes = [_i64]
-        lib.pg_nplanes.restype = _i32
-        lib.pg_nplanes.argtypes = [_i32]
+        lib.pg_ngroups.restype = _i32
+        lib.pg_ngroups.argtypes = [_i32]
+        lib.pg_nchunks.restype = _i32
+        lib.pg_nchunks.argtypes = [_i32, _i32]
         lib.pg_scan_scratch_bytes.restype = _i64
         lib.pg_scan_scratch_bytes.argtypes = [_i64]
         lib.pg_device_info.argtypes = [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32]
-        lib.pg_pack_planes.argtypes = [_vp, _i32, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp]
+        lib.pg_pack_planes.argtypes = [_vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _i64, _vp, _vp]
         lib.pg_hamming_dense.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i64, _vp]
         lib.pg_eps_slots.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
                                      _vp, _vp, _vp, _vp]
@@ -118,27 +120,33 @@ def npad(n):
     return ((max(int(n), 1) + 255) // 256) * 256
 
 
-def nplanes(l):
-    return (max(int(l), 1) + 15) // 16
+def ngroups(l):
+    return (max(int(l), 1) + 31) // 32
+
+
+def nchunks(l, bits):
+    return (ngroups(l) * int(bits) + 3) // 4
 
 
 class Planes:
-    """Device-resident token matrix in plane layout (see include/prograph_hip.h)."""
-    __slots__ = ("buf", "n", "l", "npad", "q", "alpha", "max_flags")
+    """Device-resident token matrix as bit-sliced records (see include/prograph_hip.h)."""
+    __slots__ = ("buf", "n", "l", "npad", "g", "q", "bits")
 
-    def __init__(self, buf, n, l, alpha, max_flags):
-        self.buf, self.n, self.l = buf, int(n), int(l)
-        self.npad, self.q, self.alpha, self.max_flags = npad(n), nplanes(l), alpha, max_flags
+    def __init__(self, buf, n, l, bits):
+        self.buf, self.n, self.l, self.bits = buf, int(n), int(l), int(bits)
+        self.npad, self.g, self.q = npad(n), ngroups(l), nchunks(l, bits)
 
     @property
     def nbytes(self):
         return self.buf.numel()
 
 
-def pack(tokens, rows=None, alpha=None):
+def pack(tokens, rows=None, bits=None, width=None):
     """
     (N, L) integer tokens (torch tensor on the GPU, or anything np.asarray takes) -> Planes.
     `rows`: optional index list (the reference's `idxs`, prograph/prograph.py:726).
+    `bits`: 5 or 8 bit planes per token; None picks 5 when every token is <= 31, else 8.
+    `width`: pack as if the rows were zero right-padded to this length (clean_input's padding).
     Raises ValueError when a token does not fit a byte: such data is not "tokenized" and the
     caller must take the generic torch path.
     """
@@ -151,11 +159,14 @@ def pack(tokens, rows=None, alpha=None):
     if tokens.dtype not in (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64):
         raise TypeError(f"integer tokens expected, got {tokens.dtype}")
     if tokens.dtype == torch.int8:
-        tokens = tokens.view(torch.uint8) if bool((tokens >= 0).all()) else tokens.to(torch.int16)
+        tokens = tokens.to(torch.int16)
     tokens = tokens.to(dev).contiguous()
     n_src, l = tokens.shape
-    if l > MAX_L:
-        raise ValueError(f"L={l} exceeds the native limit of {MAX_L}")
+    lw = l if width is None else int(width)
+    if lw < l:
+        raise ValueError("width smaller than the token matrix")
+    if lw > MAX_L:
+        raise ValueError(f"L={lw} exceeds the native limit of {MAX_L}")
     ridx = None
     n = n_src
     if rows is not None:
@@ -164,28 +175,29 @@ def pack(tokens, rows=None, alpha=None):
             raise IndexError("row index out of range")
         ridx = torch.where(ridx < 0, ridx + n_src, ridx).to(dev)
         n = int(ridx.numel())
-    if n == 0:
+    if n == 0 or l == 0:
         raise ValueError("empty token matrix")
-    np_, q = npad(n), nplanes(l)
-    buf = torch.empty(q * np_ * 16, dtype=torch.uint8, device=dev)
+    if bits is None:
+        lo, hi = int(tokens.min()), int(tokens.max())
+        if lo < 0 or hi > 255:
+            raise ValueError("tokens outside 0..255 cannot use the byte-token Hamming path")
+        bits = BITS_5 if hi <= 31 else BITS_8
+    np_ = npad(n)
+    if lw != l:
+        wide = torch.zeros((n_src, lw), dtype=tokens.dtype, device=dev)   # clean_input's zero right-padding
+        wide[:, :l] = tokens
+        tokens = wide
+    buf = torch.empty(nchunks(lw, bits) * np_ * 16, dtype=torch.uint8, device=dev)
     flags = torch.zeros(1, dtype=torch.int32, device=dev)
-    _check(L.pg_pack_planes(_ptr(tokens), tokens.element_size(), n, l, tokens.stride(0), _ptr(ridx), _ptr(buf), np_,
-                            _ptr(flags), _stream()), "pg_pack_planes")
-    f = int(flags.item())
-    if f & 2:
-        raise ValueError("tokens outside 0..255 cannot use the byte-token Hamming path")
-    if alpha is None:
-        if f & 1:
-            alpha = ALPHA_8BIT
-        else:
-            alpha = ALPHA_7BIT
-    return Planes(buf, n, l, alpha, f)
+    _check(L.pg_pack_planes(_ptr(tokens), tokens.element_size(), n, lw, tokens.stride(0), _ptr(ridx), int(bits),
+                            _ptr(buf), np_, _ptr(flags), _stream()), "pg_pack_planes")
+    if int(flags.item()):
+        raise ValueError(f"tokens outside 0..{(1 << bits) - 1} cannot be packed with {bits} bit planes")
+    return Planes(buf, n, lw, bits)
 
 
 def refine_alpha(planes, max_token):
-    """Callers that know the alphabet size (Prograph: len(amino_acids)) pick the 5-bit counter."""
-    if max_token <= 31 and planes.alpha == ALPHA_7BIT:
-        planes.alpha = ALPHA_5BIT
+    """Kept for callers that pass the alphabet size; the plane count is already fixed at pack time."""
     return planes
 
 
@@ -194,17 +206,18 @@ _TORCH_OUT = {1: torch.uint8, 4: torch.int32, 8: torch.int64}
 
 def hamming_dense(xp, yp, out_bytes=8):
     """(M, N) distance matrix of every row of `yp` against every row of `xp` (hamming.py:34)."""
-    if xp.q != yp.q:
-        raise ValueError("operands must be packed with the same padded length")
+    if xp.g != yp.g or xp.bits != yp.bits:
+        raise ValueError("operands must be packed with the same width and bit planes")
     out = torch.empty((yp.n, xp.n), dtype=_TORCH_OUT[out_bytes], device=xp.buf.device)
-    alpha = max(xp.alpha, yp.alpha)
-    _check(lib().pg_hamming_dense(_ptr(xp.buf), xp.n, xp.npad, _ptr(yp.buf), yp.n, yp.npad, xp.q * 16, alpha,
+    _check(lib().pg_hamming_dense(_ptr(xp.buf), xp.n, xp.npad, _ptr(yp.buf), yp.n, yp.npad, xp.g * 32, xp.bits,
                                   _ptr(out), out_bytes, out.stride(0), _stream()), "pg_hamming_dense")
     return out
 
 
-def _alpha2(rp, cp):
-    return max(rp.alpha, cp.alpha)
+def _bits2(rp, cp):
+    if rp.bits != cp.bits or rp.g != cp.g:
+        raise ValueError("row and column operands must be packed with the same width and bit planes")
+    return rp.bits
 
 
 def eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
@@ -216,14 +229,14 @@ def eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
     L = lib()
     nrows = rp.n - row0 if nrows is None else int(nrows)
     dev = rp.buf.device
-    alpha = _alpha2(rp, cp)
+    bits = _bits2(rp, cp)
     cap = int(cap)
     slot_idx = torch.empty(nrows * cap, dtype=torch.int32, device=dev)
     slot_w = torch.empty(nrows * cap, dtype=torch.uint8, device=dev)
     counts = torch.empty(nrows, dtype=torch.int32, device=dev)
     indptr = torch.empty(nrows + 1, dtype=torch.int64, device=dev)
     scratch = torch.empty(int(L.pg_scan_scratch_bytes(nrows)), dtype=torch.uint8, device=dev)
-    args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.q * 16, alpha, cmp, float(eps), cap)
+    args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, bits, cmp, float(eps), cap)
     _check(L.pg_eps_slots(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _stream()), "pg_eps_slots")
     _check(L.pg_exclusive_scan(_ptr(counts), nrows, _ptr(indptr), _ptr(scratch), _stream()), "pg_exclusive_scan")
     nnz = int(indptr[-1].item())
@@ -237,7 +250,7 @@ def eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
 
 def eps_slots_only(rp, cp, cmp, eps, row0, nrows, cap, slot_idx, slot_w, counts):
     """Just the N^2 launch on preallocated buffers (bench.py times this)."""
-    args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.q * 16, _alpha2(rp, cp), cmp,
+    args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, _bits2(rp, cp), cmp,
             float(eps), int(cap))
     _check(lib().pg_eps_slots(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _stream()), "pg_eps_slots")
 
@@ -251,14 +264,15 @@ def knn_graph(rp, cp, k, row0=0, nrows=None, out=None):
         dist = torch.empty((nrows, k), dtype=torch.uint8, device=dev)
     else:
         idx, dist = out
-    _check(lib().pg_knn_hamming(_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.q * 16,
-                                _alpha2(rp, cp), int(k), _ptr(idx), _ptr(dist), _stream()), "pg_knn_hamming")
+    _check(lib().pg_knn_hamming(_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32,
+                                _bits2(rp, cp), int(k), _ptr(idx), _ptr(dist), _stream()), "pg_knn_hamming")
     return idx, dist
 
 
 def index_flags(planes, ref, want=None, pos_mode=0, pos_mask=None, not_mask=None, want_dist_out=True,
                 want_hist=True, want_flags=True):
-    """Fused 1xN pass of Prograph.indexing; returns (dist uint8[n] | None, hist int64[256] | None, flags | None)."""
+    """Fused 1xN pass of Prograph.indexing; returns (dist uint8[n] | None, hist int64[256] | None, flags | None).
+    `pos_mask` / `not_mask` are iterables of positions (selected / must-not-differ)."""
     dev = planes.buf.device
     n = planes.n
     dist = torch.empty(n, dtype=torch.uint8, device=dev) if want_dist_out else None
@@ -274,14 +288,23 @@ def index_flags(planes, ref, want=None, pos_mode=0, pos_mask=None, not_mask=None
         wt = torch.from_numpy(bits.view(np.int32)).to(dev)
     pm = nm = None
     if pos_mode:
-        pm = torch.from_numpy(np.ascontiguousarray(pos_mask, dtype=np.uint8)).to(dev)
-        nm = torch.from_numpy(np.ascontiguousarray(not_mask, dtype=np.uint8)).to(dev)
-        assert pm.numel() == planes.q * 16 and nm.numel() == planes.q * 16
-    alpha = ALPHA_8BIT if planes.alpha == ALPHA_8BIT else ALPHA_7BIT
-    _check(lib().pg_index_flags(_ptr(planes.buf), n, planes.npad, planes.q * 16, alpha, int(ref), _ptr(wt),
+        pm = torch.from_numpy(position_bitmask(pos_mask, planes.g).view(np.int32)).to(dev)
+        nm = torch.from_numpy(position_bitmask(not_mask, planes.g).view(np.int32)).to(dev)
+    _check(lib().pg_index_flags(_ptr(planes.buf), n, planes.npad, planes.g * 32, planes.bits, int(ref), _ptr(wt),
                                 int(pos_mode), _ptr(pm), _ptr(nm), _ptr(dist), _ptr(hist), _ptr(flags), _stream()),
            "pg_index_flags")
     return dist, hist, flags
+
+
+def position_bitmask(positions, g):
+    """uint32[g] with bit j of word w set for every position 32w+j in `positions`."""
+    out = np.zeros(g, dtype=np.uint32)
+    for p in positions:
+        p = int(p)
+        if not 0 <= p < 32 * g:
+            raise IndexError(f"position {p} outside the packed width {32 * g}")
+        out[p >> 5] |= np.uint32(1 << (p & 31))
+    return out
 
 
 def compact_flags(flags):

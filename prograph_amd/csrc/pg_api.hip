@@ -23,13 +23,6 @@ static int launched(int rc, const char *where) {
   return 0;
 }
 
-static MisK make_k() {
-  MisK k;
-  k.k7f = 0x7f7f7f7fu; k.k3f = 0x3f3f3f3fu; k.k1f = 0x1f1f1f1fu;
-  k.m80 = 0x80808080u; k.mc0 = 0xc0c0c0c0u; k.me0 = 0xe0e0e0e0u;
-  return k;
-}
-
 static int g_cus = 0;
 static int cu_count() {
   if (g_cus > 0) return g_cus;
@@ -43,7 +36,7 @@ static int cu_count() {
 // waves per CU the all-pairs engine is sized for (PG_WAVES_PER_CU overrides; multiples of 4)
 static int waves_per_cu() {
   const char *e = getenv("PG_WAVES_PER_CU");
-  int w = e ? atoi(e) : 8;
+  int w = e ? atoi(e) : 16;
   if (w < 4) w = 4;
   if (w > 32) w = 32;
   return (w / 4) * 4;
@@ -68,38 +61,45 @@ int pg_device_info(int *cus, int *wave, char *arch, int arch_len) {
 }
 
 int64_t pg_npad(int64_t n) { return n <= 0 ? 256 : ((n + 255) / 256) * 256; }
-int pg_nplanes(int l) { return l <= 0 ? 1 : (l + 15) / 16; }
+int pg_ngroups(int l) { return l <= 0 ? 1 : (l + 31) / 32; }
+int pg_nchunks(int l, int bits) { return (pg_ngroups(l) * bits + 3) / 4; }
 
 }  // extern "C"
 
 // =======================================================================================
-// pack: row-major tokens -> planes
+// pack: row-major tokens -> bit-sliced records in chunk-major order (one thread per sequence)
 // =======================================================================================
-template <typename T>
+template <typename T, int B>
 __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src, long long n, int l, long long ld,
-                                                      const long long *__restrict__ rows, uint4 *__restrict__ planes,
-                                                      long long npad, int nq, u32 *flags) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= npad * nq) return;
-  const long long s = idx % npad;
-  const int q = (int)(idx / npad);
-  u32 w[4] = {0, 0, 0, 0};
+                                                      const long long *__restrict__ rows, u32 *__restrict__ planes,
+                                                      long long npad, int ng, int nq, u32 *flags) {
+  const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= npad) return;
+  const T *row = nullptr;
+  if (s < n) row = src + (rows ? rows[s] : s) * ld;
   u32 bad = 0;
-  if (s < n) {
-    const long long r = rows ? rows[s] : s;
-    const T *row = src + r * ld;
+  for (int g = 0; g < ng; ++g) {
+    u32 pl[B];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int pos = q * 16 + j;
-      if (pos < l) {
-        const long long v = (long long)row[pos];
-        if (v > 127) bad |= 1u;
-        if (v < 0 || v > 255) bad |= 2u;
-        w[j >> 2] |= ((u32)v & 0xffu) << (8 * (j & 3));
+    for (int p = 0; p < B; ++p) pl[p] = 0;
+    if (row) {
+      for (int j = 0; j < 32; ++j) {
+        const int pos = g * 32 + j;
+        if (pos < l) {
+          const long long v = (long long)row[pos];
+          if (v < 0 || v >= (1ll << B)) bad = 1u;
+#pragma unroll
+          for (int p = 0; p < B; ++p) pl[p] |= (u32)((v >> p) & 1) << j;
+        }
       }
     }
+#pragma unroll
+    for (int p = 0; p < B; ++p) {
+      const int w = g * B + p;
+      planes[((long long)(w >> 2) * npad + s) * 4 + (w & 3)] = pl[p];
+    }
   }
-  planes[(long long)q * npad + s] = make_uint4(w[0], w[1], w[2], w[3]);
+  for (int w = ng * B; w < nq * 4; ++w) planes[((long long)(w >> 2) * npad + s) * 4 + (w & 3)] = 0;
   if (bad) atomicOr(flags, bad);
 }
 
@@ -186,12 +186,12 @@ __global__ __launch_bounds__(256) void pg_scan_apply(const T *__restrict__ in, l
 }
 
 // =======================================================================================
-// fused 1xN indexing pass
+// fused 1xN indexing pass (one thread per sequence; position masks are bitmasks per group)
 // =======================================================================================
-template <int ALPHA>
-__global__ __launch_bounds__(256) void pg_index_kernel(const uint4 *__restrict__ planes, long long n, long long npad, int nq,
+template <int B>
+__global__ __launch_bounds__(256) void pg_index_kernel(const u32 *__restrict__ planes, long long n, long long npad, int ng,
                                                        long long ref, const u32 *__restrict__ want, int posMode,
-                                                       const uint4 *__restrict__ posMask, const uint4 *__restrict__ notMask,
+                                                       const u32 *__restrict__ posMask, const u32 *__restrict__ notMask,
                                                        unsigned char *distOut, u64 *hist, unsigned char *flags) {
   __shared__ u32 lh[256];
   lh[threadIdx.x] = 0;
@@ -200,18 +200,20 @@ __global__ __launch_bounds__(256) void pg_index_kernel(const uint4 *__restrict__
   if (s < n) {
     u32 d = 0, anyP = 0, anyNot = 0;
     bool allP = true;
-    for (int q = 0; q < nq; ++q) {
-      const uint4 c = planes[(long long)q * npad + s];
-      const uint4 r = planes[(long long)q * npad + ref];
-      const u32 f0 = mis_flags<ALPHA>(c.x, r.x), f1 = mis_flags<ALPHA>(c.y, r.y);
-      const u32 f2 = mis_flags<ALPHA>(c.z, r.z), f3 = mis_flags<ALPHA>(c.w, r.w);
-      d += __builtin_popcount(f0) + __builtin_popcount(f1) + __builtin_popcount(f2) + __builtin_popcount(f3);
+    for (int g = 0; g < ng; ++g) {
+      u32 t = 0;
+#pragma unroll
+      for (int p = 0; p < B; ++p) {
+        const int w = g * B + p;
+        const long long base = (long long)(w >> 2) * npad;
+        t |= planes[(base + s) * 4 + (w & 3)] ^ planes[(base + ref) * 4 + (w & 3)];
+      }
+      d += __builtin_popcount(t);
       if (posMode) {
-        const uint4 pm = posMask[q], nm = notMask[q];
-        anyP |= (f0 & pm.x) | (f1 & pm.y) | (f2 & pm.z) | (f3 & pm.w);
-        allP = allP && ((f0 & pm.x) == (0x80808080u & pm.x)) && ((f1 & pm.y) == (0x80808080u & pm.y)) &&
-               ((f2 & pm.z) == (0x80808080u & pm.z)) && ((f3 & pm.w) == (0x80808080u & pm.w));
-        anyNot |= (f0 & nm.x) | (f1 & nm.y) | (f2 & nm.z) | (f3 & nm.w);
+        const u32 pm = posMask[g], nm = notMask[g];
+        anyP |= t & pm;
+        allP = allP && ((t & pm) == pm);
+        anyNot |= t & nm;
       }
     }
     if (distOut) distOut[s] = (unsigned char)d;
@@ -235,8 +237,8 @@ static int check_l(int l) {
   if (l > PG_MAX_L) return fail(PG_E_TOOLONG, "sequence length exceeds PG_MAX_L (128 bytes)");
   return 0;
 }
-static int check_alpha(int a) {
-  if (a != 5 && a != PG_ALPHA_7BIT && a != PG_ALPHA_8BIT) return fail(PG_E_BADARG, "alpha must be 5, 7 or 8");
+static int check_bits(int b) {
+  if (b != PG_BITS_5 && b != PG_BITS_8) return fail(PG_E_BADARG, "bits must be 5 or 8");
   return 0;
 }
 
@@ -264,13 +266,10 @@ static void eps_interval(int cmp, double eps, u32 *lo, u32 *span) {
 typedef int (*nsq_fn)(int, int, const NsqParams &, int, hipStream_t);
 typedef int (*dense_fn)(int, const DenseParams &, hipStream_t);
 typedef int (*compact_fn)(int, const CompactParams &, hipStream_t);
-static const nsq_fn kNsq[8] = {pg_launch_nsq_q1, pg_launch_nsq_q2, pg_launch_nsq_q3, pg_launch_nsq_q4,
-                               pg_launch_nsq_q5, pg_launch_nsq_q6, pg_launch_nsq_q7, pg_launch_nsq_q8};
-static const dense_fn kDense[8] = {pg_launch_dense_q1, pg_launch_dense_q2, pg_launch_dense_q3, pg_launch_dense_q4,
-                                   pg_launch_dense_q5, pg_launch_dense_q6, pg_launch_dense_q7, pg_launch_dense_q8};
-static const compact_fn kCompact[8] = {pg_launch_compact_q1, pg_launch_compact_q2, pg_launch_compact_q3,
-                                       pg_launch_compact_q4, pg_launch_compact_q5, pg_launch_compact_q6,
-                                       pg_launch_compact_q7, pg_launch_compact_q8};
+static const nsq_fn kNsq[4] = {pg_launch_nsq_g1, pg_launch_nsq_g2, pg_launch_nsq_g3, pg_launch_nsq_g4};
+static const dense_fn kDense[4] = {pg_launch_dense_g1, pg_launch_dense_g2, pg_launch_dense_g3, pg_launch_dense_g4};
+static const compact_fn kCompact[4] = {pg_launch_compact_g1, pg_launch_compact_g2, pg_launch_compact_g3,
+                                       pg_launch_compact_g4};
 
 // Static, even split of the rows over the resident waves: every row costs the same (one
 // sweep over all columns), so equal row counts are equal work.  Each wave then walks its
@@ -291,73 +290,77 @@ static int plan_rows(int64_t nrows, NsqParams *p, int *grid) {
 
 extern "C" {
 
-int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld, const int64_t *rows, void *planes,
-                   int64_t npad, uint32_t *flags, void *stream) {
+int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld, const int64_t *rows, int bits,
+                   void *planes, int64_t npad, uint32_t *flags, void *stream) {
   if (!src || !planes || !flags || n < 0 || ld < l) return fail(PG_E_BADARG, "pg_pack_planes: bad argument");
   if (int rc = check_l(l)) return rc;
+  if (int rc = check_bits(bits)) return rc;
   if (npad < n || npad % 256) return fail(PG_E_BADARG, "pg_pack_planes: npad must be pg_npad(n)");
-  const int nq = pg_nplanes(l);
+  const int ng = pg_ngroups(l), nq = pg_nchunks(l, bits);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t), s);
   if (e != hipSuccess) return hipfail(e, "hipMemsetAsync");
-  const long long total = npad * nq;
-  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  const dim3 grid((unsigned)((npad + 255) / 256)), block(256);
   const long long *r = (const long long *)rows;
-  uint4 *pl = (uint4 *)planes;
+  u32 *pl = (u32 *)planes;
+#define PG_PACK(T)                                                                                          \
+  do {                                                                                                      \
+    if (bits == 5) pg_pack_kernel<T, 5><<<grid, block, 0, s>>>((const T *)src, n, l, ld, r, pl, npad, ng, nq, flags); \
+    else pg_pack_kernel<T, 8><<<grid, block, 0, s>>>((const T *)src, n, l, ld, r, pl, npad, ng, nq, flags); \
+  } while (0)
   switch (elem_bytes) {
-    case 1: pg_pack_kernel<unsigned char><<<grid, block, 0, s>>>((const unsigned char *)src, n, l, ld, r, pl, npad, nq, flags); break;
-    case 2: pg_pack_kernel<short><<<grid, block, 0, s>>>((const short *)src, n, l, ld, r, pl, npad, nq, flags); break;
-    case 4: pg_pack_kernel<int><<<grid, block, 0, s>>>((const int *)src, n, l, ld, r, pl, npad, nq, flags); break;
-    case 8: pg_pack_kernel<long long><<<grid, block, 0, s>>>((const long long *)src, n, l, ld, r, pl, npad, nq, flags); break;
+    case 1: PG_PACK(unsigned char); break;
+    case 2: PG_PACK(short); break;
+    case 4: PG_PACK(int); break;
+    case 8: PG_PACK(long long); break;
     default: return fail(PG_E_BADARG, "pg_pack_planes: elem_bytes must be 1, 2, 4 or 8");
   }
+#undef PG_PACK
   return launched((int)hipGetLastError(), "pg_pack_kernel");
 }
 
 int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad, const void *y_planes, int64_t m, int64_t y_npad,
-                     int l, int alpha, void *out, int out_elem_bytes, int64_t ldo, void *stream) {
+                     int l, int bits, void *out, int out_elem_bytes, int64_t ldo, void *stream) {
   if (!x_planes || !y_planes || !out || n <= 0 || m <= 0 || ldo < n)
     return fail(PG_E_BADARG, "pg_hamming_dense: bad argument");
   if (int rc = check_l(l)) return rc;
-  if (int rc = check_alpha(alpha)) return rc;
+  if (int rc = check_bits(bits)) return rc;
   if (out_elem_bytes != 1 && out_elem_bytes != 4 && out_elem_bytes != 8)
     return fail(PG_E_BADARG, "pg_hamming_dense: out_elem_bytes must be 1, 4 or 8");
   if (x_npad < n || x_npad % 256 || y_npad < m) return fail(PG_E_BADARG, "pg_hamming_dense: bad npad");
   if ((m + PG_RBD - 1) / PG_RBD > 65535) return fail(PG_E_BADARG, "pg_hamming_dense: m too large for one launch");
   DenseParams p;
-  p.K = make_k();
   p.xPlanes = (const uint4 *)x_planes; p.xNpad = x_npad; p.n = n;
   p.yPlanes = (const uint4 *)y_planes; p.yNpad = y_npad; p.m = m;
   p.out = out; p.ldo = ldo; p.outBytes = out_elem_bytes;
-  return launched(kDense[pg_nplanes(l) - 1](alpha, p, (hipStream_t)stream), "pg_dense_kernel");
+  return launched(kDense[pg_ngroups(l) - 1](bits, p, (hipStream_t)stream), "pg_dense_kernel");
 }
 
 static int fill_nsq(NsqParams *p, const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
-                    const void *col_planes, int64_t col_npad, int64_t ncols, int l, int alpha) {
+                    const void *col_planes, int64_t col_npad, int64_t ncols, int l, int bits) {
   if (!row_planes || !col_planes || row0 < 0 || nrows <= 0 || ncols <= 0) return fail(PG_E_BADARG, "bad argument");
   if (int rc = check_l(l)) return rc;
-  if (int rc = check_alpha(alpha)) return rc;
+  if (int rc = check_bits(bits)) return rc;
   if (col_npad < ncols || col_npad % 256 || row_npad < row0 + nrows) return fail(PG_E_BADARG, "bad npad");
   if (ncols > 0x7fffffffLL) return fail(PG_E_TOOMANY, "ncols exceeds int32 indices");
   memset(p, 0, sizeof(*p));
-  p->K = make_k();
   p->rowPlanes = (const uint4 *)row_planes; p->rowNpad = row_npad; p->row0 = row0; p->nrows = nrows;
   p->colPlanes = (const uint4 *)col_planes; p->colNpad = col_npad; p->ncols = ncols;
   return 0;
 }
 
 int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
-                 int64_t col_npad, int64_t ncols, int l, int alpha, int cmp, double eps, int cap, int32_t *slot_idx,
+                 int64_t col_npad, int64_t ncols, int l, int bits, int cmp, double eps, int cap, int32_t *slot_idx,
                  uint8_t *slot_w, uint32_t *counts, void *stream) {
   NsqParams p;
-  if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, alpha)) return rc;
+  if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits)) return rc;
   if (!slot_idx || !slot_w || !counts || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
     return fail(PG_E_BADARG, "pg_eps_slots: bad argument");
   eps_interval(cmp, eps, &p.lo, &p.span);
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
   int grid = 0;
   if (int rc = plan_rows(nrows, &p, &grid)) return rc;
-  return launched(kNsq[pg_nplanes(l) - 1](PG_MODE_EPS, alpha, p, grid, (hipStream_t)stream), "pg_nsq_kernel(eps)");
+  return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(eps)");
 }
 
 int64_t pg_scan_scratch_bytes(int64_t n) {
@@ -377,11 +380,11 @@ int pg_exclusive_scan(const uint32_t *counts, int64_t n, int64_t *indptr, void *
 }
 
 int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
-                   int64_t col_npad, int64_t ncols, int l, int alpha, int cmp, double eps, int cap,
+                   int64_t col_npad, int64_t ncols, int l, int bits, int cmp, double eps, int cap,
                    const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts, const int64_t *indptr,
                    int32_t *indices, uint8_t *weights, void *stream) {
   CompactParams c;
-  if (int rc = fill_nsq(&c.e, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, alpha)) return rc;
+  if (int rc = fill_nsq(&c.e, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits)) return rc;
   if (!slot_idx || !slot_w || !counts || !indptr || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
     return fail(PG_E_BADARG, "pg_eps_compact: bad argument");
   eps_interval(cmp, eps, &c.e.lo, &c.e.span);
@@ -390,41 +393,39 @@ int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64
   c.e.slotW = const_cast<unsigned char *>(slot_w);
   c.e.counts = const_cast<u32 *>(counts);
   c.indptr = (const long long *)indptr; c.indices = indices; c.weights = weights;
-  return launched(kCompact[pg_nplanes(l) - 1](alpha, c, (hipStream_t)stream), "pg_compact_kernel");
+  return launched(kCompact[pg_ngroups(l) - 1](bits, c, (hipStream_t)stream), "pg_compact_kernel");
 }
 
 int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
-                   int64_t col_npad, int64_t ncols, int l, int alpha, int k, int32_t *idx_out, uint8_t *dist_out,
+                   int64_t col_npad, int64_t ncols, int l, int bits, int k, int32_t *idx_out, uint8_t *dist_out,
                    void *stream) {
   NsqParams p;
-  if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, alpha)) return rc;
+  if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits)) return rc;
   if (!idx_out || !dist_out) return fail(PG_E_BADARG, "pg_knn_hamming: bad argument");
   if (k < 1 || k > PG_MAX_K) return fail(PG_E_BADARG, "pg_knn_hamming: k must be in 1..63");
   if (ncols > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_knn_hamming: ncols exceeds 2^24");
   p.k = k; p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;
   if (int rc = plan_rows(nrows, &p, &grid)) return rc;
-  return launched(kNsq[pg_nplanes(l) - 1](PG_MODE_KNN, alpha, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");
+  return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");
 }
 
-int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int alpha, int64_t ref,
-                   const uint32_t *want_dist, int pos_mode, const uint8_t *pos_mask, const uint8_t *not_mask,
+int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int bits, int64_t ref,
+                   const uint32_t *want_dist, int pos_mode, const uint32_t *pos_mask, const uint32_t *not_mask,
                    uint8_t *dist_out, uint64_t *hist, uint8_t *flags, void *stream) {
   if (!planes || n <= 0 || npad < n || ref < 0 || ref >= n) return fail(PG_E_BADARG, "pg_index_flags: bad argument");
   if (int rc = check_l(l)) return rc;
-  if (int rc = check_alpha(alpha)) return rc;
+  if (int rc = check_bits(bits)) return rc;
   if (pos_mode < 0 || pos_mode > 2 || (pos_mode && (!pos_mask || !not_mask)))
     return fail(PG_E_BADARG, "pg_index_flags: bad position mode / masks");
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (alpha == PG_ALPHA_8BIT)
-    pg_index_kernel<8><<<grid, block, 0, s>>>((const uint4 *)planes, n, npad, pg_nplanes(l), ref, want_dist, pos_mode,
-                                              (const uint4 *)pos_mask, (const uint4 *)not_mask, dist_out,
-                                              (u64 *)hist, flags);
+  if (bits == 5)
+    pg_index_kernel<5><<<grid, block, 0, s>>>((const u32 *)planes, n, npad, pg_ngroups(l), ref, want_dist, pos_mode,
+                                              pos_mask, not_mask, dist_out, (u64 *)hist, flags);
   else
-    pg_index_kernel<7><<<grid, block, 0, s>>>((const uint4 *)planes, n, npad, pg_nplanes(l), ref, want_dist, pos_mode,
-                                              (const uint4 *)pos_mask, (const uint4 *)not_mask, dist_out,
-                                              (u64 *)hist, flags);
+    pg_index_kernel<8><<<grid, block, 0, s>>>((const u32 *)planes, n, npad, pg_ngroups(l), ref, want_dist, pos_mode,
+                                              pos_mask, not_mask, dist_out, (u64 *)hist, flags);
   return launched((int)hipGetLastError(), "pg_index_kernel");
 }
 

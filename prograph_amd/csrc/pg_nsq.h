@@ -4,28 +4,28 @@
 // :756-762 of the reference): distance(X, batch) -> mask/where or sort -> gather.
 //
 // Mapping (CDNA4, wave64):
-//   * one LANE owns one COLUMN sequence: its Q 16-byte chunks sit in VGPRs, loaded from
-//     the plane layout as fully coalesced global_load_dwordx4 (1 KiB per wave instruction);
-//     the next column tile is prefetched into a second register set while the current
-//     one is being compared;
+//   * one LANE owns C COLUMN sequences: their bit-sliced records (pg_common.h) sit in VGPRs,
+//     loaded from the chunk-major layout as fully coalesced global_load_dwordx4 (1 KiB per wave
+//     instruction); the next column tile is prefetched into a second register set while the
+//     current one is being compared;
 //   * one WAVE owns a block of up to RB=16 ROW sequences, staged once per pass into a
 //     wave-private LDS region and read back as broadcast ds_read_b128 (all lanes the same
-//     address), so the row operand costs 4 LDS cycles per 16 bytes per 64*B pairs;
-//   * the wave sweeps ALL column tiles in ascending order for its rows, therefore every
-//     row's matches are produced in ascending column order by exactly one wave: the
-//     reference's `torch.where` order (prograph/prograph.py:736) without any sort, and the
-//     canonical (distance, index) kNN order without a merge;
-//   * per pair-step the epilogue is 2 VALU ops (range test or packed-key compare) and a
-//     wave-uniform branch on the ballot; compaction (mbcnt) and sorted insertion (DPP
-//     wave_shr + v_readlane) only run in the rarely taken slow path.
-// No MFMA: the inner loop is byte compares (xor / add / and / popcount), 3 VALU ops per
-// 4 tokens; the operand matrix is cache resident, see DESIGN.md for the roofline.
+//     address): the row operand costs a few LDS cycles per 64*C pairs;
+//   * the wave sweeps ALL column tiles in ascending order for its rows, therefore every row's
+//     matches are produced in ascending column order by exactly one wave: the reference's
+//     `torch.where` order (prograph/prograph.py:736) without any sort, and the canonical
+//     (distance, index) kNN order without a merge;
+//   * per row-step (64*C pairs) the epilogue is C-1 v_min + 1 v_cmp and ONE wave-uniform
+//     branch on the ballot; compaction (mbcnt) and sorted insertion (DPP wave_shr + v_readlane)
+//     only run in the rarely taken slow path.
+// No MFMA: the inner loop is boolean bit-plane logic (xor / bitop3 / popcount), B+1 VALU ops per
+// 32 tokens; the operand matrix is cache resident, see DESIGN.md for the roofline.
 #pragma once
 #include "pg_common.h"
 
-
-template <int Q, int B, int ALPHA, int MODE>
+template <int G, int B, int C, int MODE>
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p) {
+  constexpr int Q = Rec<G, B>::Q;
   __shared__ uint4 rowbuf[PG_WG_WAVES][PG_RB][Q];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -33,17 +33,20 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
   const long long wr0 = gw * p.rowsPerWave;
   if (wr0 >= p.nrows) return;   // whole wave leaves; no workgroup barrier is used below
   const long long wr1 = (wr0 + p.rowsPerWave < p.nrows) ? wr0 + p.rowsPerWave : p.nrows;
-  const long long ntiles = (p.ncols + 64 * B - 1) / (64 * B);
+  const long long ntiles = (p.ncols + 64 * C - 1) / (64 * C);
   const uint4 *__restrict__ colp = p.colPlanes;
   const u32 ncols = (u32)p.ncols;
   const uint4 *rows = &rowbuf[wv][0][0] + opaque_zero();   // broadcast reads, kept "divergent"
+  // eps: the bias -lo seeds the popcount accumulator (v_bcnt's addend) from an opaque VGPR, so
+  // hipcc cannot re-associate it into an extra v_sub per pair
+  const u32 bias = MODE == PG_MODE_EPS ? opaque_vgpr(0u - p.lo) : 0u;
 
   for (long long pr0 = wr0; pr0 < wr1; pr0 += p.rowsPerPass) {
     const long long left = wr1 - pr0;
     const int nr = __builtin_amdgcn_readfirstlane((int)(left < p.rowsPerPass ? left : p.rowsPerPass));
 
     // ---- stage this pass's rows into the wave's LDS region (wave private: LDS operations
-    // of one wave are processed in order, the fence only pins the compiler) ----
+    // of one wave are processed in order, the fences only pin the compiler) ----
     for (int e = lane; e < PG_RB * Q; e += 64) {
       const int rr = e % PG_RB, q = e / PG_RB;
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -60,9 +63,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 #pragma unroll
     for (int rr = 0; rr < PG_RB; ++rr) { cnt[rr] = 0; thr[rr] = 0xFFFFFFFFu; lst[rr] = 0xFFFFFFFFu; }
 
-    uint4 c[B][Q], cn[B][Q];
+    uint4 c[C][Q], cn[C][Q];
 #pragma unroll
-    for (int b = 0; b < B; ++b)
+    for (int b = 0; b < C; ++b)
 #pragma unroll
       for (int q = 0; q < Q; ++q) c[b][q] = colp[(long long)q * p.colNpad + b * 64 + lane];
 
@@ -71,11 +74,11 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
       // own tile) so that the compiler's waitcnt pass can keep it in flight across the rows
       const long long tn = (t + 1 < ntiles) ? t + 1 : t;
 #pragma unroll
-      for (int b = 0; b < B; ++b)
+      for (int b = 0; b < C; ++b)
 #pragma unroll
         for (int q = 0; q < Q; ++q)
-          cn[b][q] = colp[(long long)q * p.colNpad + tn * (64 * B) + b * 64 + lane];
-      const u32 col0 = (u32)(t * (64 * B)) + lane;
+          cn[b][q] = colp[(long long)q * p.colNpad + tn * (64 * C) + b * 64 + lane];
+      const u32 col0 = (u32)(t * (64 * C)) + lane;
 
       uint4 r[Q], rn[Q];
 #pragma unroll
@@ -88,33 +91,36 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 #pragma unroll
             for (int q = 0; q < Q; ++q) rn[q] = rows[(rr + 1) * Q + q];
           }
+          // eps: (comp(d, eps) & (d > 0)) is one unsigned range test lo <= d <= lo+span; the
+          //      bias -lo rides in the popcount accumulator.
+          // knn: keys are (distance << 24 | column); columns only grow along the sweep, so a
+          //      candidate beats the current (k+1)-th key iff its distance is strictly smaller.
+          u32 d[C];
 #pragma unroll
-          for (int b = 0; b < B; ++b) {
-            const u32 col = col0 + b * 64;
-            if constexpr (MODE == PG_MODE_EPS) {
-              // (comp(d, eps) & (d > 0)) is one unsigned range test lo <= d <= lo+span; the
-              // bias -lo rides in the popcount accumulator, leaving one v_cmp per pair
-              const u32 dl = mismatch<Q, ALPHA>(p.K, r, c[b], 0u - p.lo);
-              const bool hit = dl <= p.span;
-              if (__ballot(hit)) {
-                const bool h2 = hit && (col < ncols);
+          for (int b = 0; b < C; ++b) d[b] = mismatch<G, B>(r, c[b], bias);
+          u32 dmin = d[0];
+#pragma unroll
+          for (int b = 1; b < C; ++b) dmin = dmin < d[b] ? dmin : d[b];
+          const u32 bound = MODE == PG_MODE_EPS ? p.span + 1u : (thr[rr] >> 24);
+          if (__ballot(dmin < bound)) {
+#pragma unroll
+            for (int b = 0; b < C; ++b) {
+              const u32 col = col0 + b * 64;
+              if constexpr (MODE == PG_MODE_EPS) {
+                const bool h2 = (d[b] <= p.span) && (col < ncols);
                 const u64 m2 = __ballot(h2);
-                const u32 pos = cnt[rr] + mask_rank(m2);
-                if (h2 && pos < p.cap) {
-                  const long long o = (pr0 + rr) * (long long)p.cap + pos;
-                  p.slotIdx[o] = (int)col;
-                  p.slotW[o] = (unsigned char)(dl + p.lo);
+                if (m2) {
+                  const u32 pos = cnt[rr] + mask_rank(m2);
+                  if (h2 && pos < p.cap) {
+                    const long long o = (pr0 + rr) * (long long)p.cap + pos;
+                    p.slotIdx[o] = (int)col;
+                    p.slotW[o] = (unsigned char)(d[b] + p.lo);
+                  }
+                  cnt[rr] += (u32)__popcll(m2);
                 }
-                cnt[rr] += (u32)__popcll(m2);
-              }
-            } else {
-              // keys are (distance << 24 | column); columns only grow along the sweep, so a
-              // candidate beats the current (k+1)-th key iff its distance is strictly smaller
-              const u32 d = mismatch<Q, ALPHA>(p.K, r, c[b]);
-              const bool acc = d < (thr[rr] >> 24);
-              if (__ballot(acc)) {
-                const u32 key = (d << 24) | col;
-                u64 m = __ballot(acc && (col < ncols));
+              } else {
+                const u32 key = (d[b] << 24) | col;
+                u64 m = __ballot((d[b] < (thr[rr] >> 24)) && (col < ncols));
                 while (m) {
                   const int j = __builtin_ctzll(m);
                   m &= m - 1;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
         }
       }
 #pragma unroll
-      for (int b = 0; b < B; ++b)
+      for (int b = 0; b < C; ++b)
 #pragma unroll
         for (int q = 0; q < Q; ++q) c[b][q] = cn[b][q];
     }
@@ -160,12 +166,13 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 }
 
 // ---------------------------------------------------------------------------------------
-// Dense (M,N) distance matrix: hamming() operator parity (prograph/distance/hamming.py:34)
-// and the 1xN query of Prograph.indexing.  Output bound (8 B per pair for int64), so the
-// grid is over column tiles x row blocks and the workgroup shares one staged row block.
+// Dense (M,N) distance matrix: hamming() operator parity (prograph/distance/hamming.py:34).
+// Output bound (8 B per pair for int64), so the grid is over column tiles x row blocks and the
+// workgroup shares one staged row block.
 // ---------------------------------------------------------------------------------------
-template <int Q, int ALPHA, typename OutT>
+template <int G, int B, typename OutT>
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_dense_kernel(const DenseParams p) {
+  constexpr int Q = Rec<G, B>::Q;
   __shared__ uint4 rowbuf[PG_RBD][Q];
   const long long col = (long long)blockIdx.x * PG_WG_THREADS + threadIdx.x;
   const long long r0 = (long long)blockIdx.y * PG_RBD;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_dense_kernel(const DensePara
     uint4 r[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) r[q] = rows[rr * Q + q];
-    const u32 d = mismatch<Q, ALPHA>(p.K, r, c);
+    const u32 d = mismatch<G, B>(r, c);
     if (ok) out[(r0 + rr) * p.ldo + col] = (OutT)d;
   }
 }
@@ -196,8 +203,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_dense_kernel(const DensePara
 // Slots -> CSR, one wave per row.  Rows that overflowed their slot are recomputed here
 // with the same range test, so the result is exact for any capacity.
 // ---------------------------------------------------------------------------------------
-template <int Q, int ALPHA>
+template <int G, int B>
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_compact_kernel(const CompactParams p) {
+  constexpr int Q = Rec<G, B>::Q;
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * PG_WG_WAVES + (threadIdx.x >> 6);
   if (row >= p.e.nrows) return;
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_compact_kernel(const Compact
     uint4 c[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) c[q] = p.e.colPlanes[(long long)q * p.e.colNpad + col];
-    const u32 d = mismatch<Q, ALPHA>(p.e.K, r, c);
+    const u32 d = mismatch<G, B>(r, c);
     const bool hit = ((d - p.e.lo) <= p.e.span) && (col < p.e.ncols);
     const u64 m = __ballot(hit);
     if (hit) {

@@ -42,7 +42,8 @@ def hamming(X, Y, similarity=False):
         xb = _as_byte_tokens(Xd)
         yb = _as_byte_tokens(Yd) if xb is not None else None
     if xb is not None and yb is not None:
-        distances = _native.hamming_dense(_native.pack(xb), _native.pack(yb), out_bytes=8)
+        bits = _native.BITS_5 if max(int(xb.max()), int(yb.max())) <= 31 else _native.BITS_8
+        distances = _native.hamming_dense(_native.pack(xb, bits=bits), _native.pack(yb, bits=bits), out_bytes=8)
     else:
         distances = torch.sum(Xd != Yd[:, None, :], axis=2)
     if similarity:

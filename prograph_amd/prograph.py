@@ -239,9 +239,9 @@ class Prograph:
             mat = np.vstack(self(representation))
         if not np.issubdtype(np.asarray(mat).dtype, np.integer):
             raise ValueError("not an integer representation")
-        planes = _native.pack(torch.from_numpy(np.ascontiguousarray(mat)), rows=idxs)
-        if representation == "Tokenized":
-            _native.refine_alpha(planes, len(self.amino_acids))
+        # tokens of the built-in tokeniser are 0..len(amino_acids): 5 bit planes cover 31 letters
+        bits = _native.BITS_5 if (representation == "Tokenized" and len(self.amino_acids) <= 31) else None
+        planes = _native.pack(torch.from_numpy(np.ascontiguousarray(mat)), rows=idxs, bits=bits)
         if idxs is None:
             self._planes[key] = planes
         return planes
@@ -286,16 +286,12 @@ class Prograph:
         pos_mode, pos_mask, not_mask = 0, None, None
         if positions is not None:
             ref_len = len(self[reference_seq]["Sequence"])
-            width = planes.q * 16
-            pos_mask = np.zeros(width, dtype=np.uint8)
-            not_mask = np.zeros(width, dtype=np.uint8)
+            ncol = self.tokenized.shape[1]
             for p in positions:
-                if not -self.tokenized.shape[1] <= p < self.tokenized.shape[1]:
-                    raise IndexError(f"index {p} is out of bounds for axis 1 with size {self.tokenized.shape[1]}")
-                pos_mask[p % self.tokenized.shape[1]] = 0xFF
-            for p in range(ref_len):
-                if p not in positions:
-                    not_mask[p] = 0xFF
+                if not -ncol <= p < ncol:
+                    raise IndexError(f"index {p} is out of bounds for axis 1 with size {ncol}")
+            pos_mask = [p % ncol for p in positions]
+            not_mask = [p for p in range(ref_len) if p not in positions]
             if len(positions) == 0:
                 raise TypeError("reduce() of empty sequence with no initial value")
             pos_mode = 1 if Bool == "or" else 2

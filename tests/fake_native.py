@@ -17,19 +17,21 @@ _OPS = {_native.CMP_LE: operator.le, _native.CMP_LT: operator.lt, _native.CMP_EQ
 
 
 class FakePlanes:
-    def __init__(self, tok, alpha):
+    def __init__(self, tok, bits):
         self.tok = np.ascontiguousarray(tok).astype(np.int64)
         self.n, self.l = self.tok.shape
-        self.npad, self.q, self.alpha, self.max_flags = _native.npad(self.n), _native.nplanes(self.l), alpha, 0
+        self.npad, self.g, self.q, self.bits = _native.npad(self.n), _native.ngroups(self.l), _native.nchunks(self.l, bits), bits
         self.buf = torch.zeros(1, dtype=torch.uint8)
 
 
-def _pack(tokens, rows=None, alpha=None):
+def _pack(tokens, rows=None, bits=None, width=None):
     t = tokens.cpu().numpy() if isinstance(tokens, torch.Tensor) else np.asarray(tokens)
     if t.ndim != 2:
         raise ValueError("token matrix must be 2-D")
     if not np.issubdtype(t.dtype, np.integer):
         raise TypeError("integer tokens expected")
+    if width is not None:
+        t = _pad_to(t, width)
     if t.shape[1] > _native.MAX_L:
         raise ValueError("L exceeds the native limit")
     if rows is not None:
@@ -38,7 +40,10 @@ def _pack(tokens, rows=None, alpha=None):
         raise ValueError("tokens outside 0..255")
     if t.shape[0] == 0:
         raise ValueError("empty token matrix")
-    return FakePlanes(t, alpha or (8 if t.size and t.max() > 127 else 7))
+    bits = bits or (8 if t.size and t.max() > 31 else 5)
+    if t.size and t.max() >= (1 << bits):
+        raise ValueError("tokens do not fit the bit planes")
+    return FakePlanes(t, bits)
 
 
 def _pad_to(a, l):
@@ -92,8 +97,8 @@ def _index_flags(planes, ref, want=None, pos_mode=0, pos_mask=None, not_mask=Non
     if want is not None:
         ok &= np.isin(d, np.asarray(list(want)))
     if pos_mode:
-        pm = np.asarray(pos_mask[:planes.l]) != 0
-        nm = np.asarray(not_mask[:planes.l]) != 0
+        pm = np.zeros(planes.l, dtype=bool); pm[list(pos_mask)] = True
+        nm = np.zeros(planes.l, dtype=bool); nm[list(not_mask)] = True
         anyp = (mut & pm).any(1)
         allp = (mut | ~pm).all(1)
         ok &= (anyp if pos_mode == 1 else allp) & ~(mut & nm).any(1)

@@ -27,9 +27,10 @@ def test_header_symbols_are_bound_and_exported():
         assert hasattr(lib, name), name
     assert lib.pg_version() == _native.ABI_VERSION
     assert lib.pg_npad(1) == 256 and lib.pg_npad(256) == 256 and lib.pg_npad(257) == 512
-    assert lib.pg_nplanes(1) == 1 and lib.pg_nplanes(16) == 1 and lib.pg_nplanes(17) == 2 and lib.pg_nplanes(128) == 8
+    assert lib.pg_ngroups(1) == 1 and lib.pg_ngroups(32) == 1 and lib.pg_ngroups(33) == 2 and lib.pg_ngroups(128) == 4
+    assert lib.pg_nchunks(64, 5) == 3 and lib.pg_nchunks(32, 5) == 2 and lib.pg_nchunks(128, 8) == 8
     assert lib.pg_scan_scratch_bytes(1) >= 16
-    assert _native.npad(50_000) == lib.pg_npad(50_000) and _native.nplanes(64) == lib.pg_nplanes(64)
+    assert _native.npad(50_000) == lib.pg_npad(50_000) and _native.nchunks(64, 5) == lib.pg_nchunks(64, 5)
 
 
 def test_one_hip_runtime_in_process():
@@ -45,9 +46,9 @@ def test_argument_validation_without_gpu():
     """Library-side argument checks return PG_E_* before any launch."""
     from prograph_amd import _native
     lib = _native.lib()
-    rc = lib.pg_knn_hamming(None, 256, 0, 1, None, 256, 1, 16, 7, 4, None, None, None)
+    rc = lib.pg_knn_hamming(None, 256, 0, 1, None, 256, 1, 16, 5, 4, None, None, None)
     assert rc == -1 and b"bad argument" in lib.pg_last_error()
-    rc = lib.pg_pack_planes(ctypes.c_void_p(16), 1, 4, 300, 300, None, ctypes.c_void_p(16), 256, ctypes.c_void_p(16), None)
+    rc = lib.pg_pack_planes(ctypes.c_void_p(16), 1, 4, 300, 300, None, 5, ctypes.c_void_p(16), 256, ctypes.c_void_p(16), None)
     assert rc == -2
 
 

@@ -15,7 +15,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 SETS = ["ref_synthetic_csv", "synth_n1000_l32", "synth_n2085_l64", "synth_n515_l20_dups", "synth_n300_varlen24"]
-ALPHAS = [5, 7, 8]
+BITS = [5, 8]
 
 
 @pytest.fixture(scope="module")
@@ -26,22 +26,20 @@ def nat():
     return _native
 
 
-def _planes(nat, tok, alpha, rows=None):
-    p = nat.pack(torch.from_numpy(np.ascontiguousarray(tok)), rows=rows)
-    p.alpha = alpha
-    return p
+def _planes(nat, tok, bits, rows=None):
+    return nat.pack(torch.from_numpy(np.ascontiguousarray(tok)), rows=rows, bits=bits)
 
 
 def _csr_np(t):
     return [x.cpu().numpy() for x in t]
 
 
-@pytest.mark.parametrize("alpha", ALPHAS)
+@pytest.mark.parametrize("bits", BITS)
 @pytest.mark.parametrize("name", SETS)
-def test_eps_golden(nat, name, alpha):
+def test_eps_golden(nat, name, bits):
     g = load_golden(name)
     tok = g["tokens"]
-    p = _planes(nat, tok, alpha)
+    p = _planes(nat, tok, bits)
     for key in g.files:
         if not key.endswith("_indptr") or "sub" in key or "sim" in key or "_b5" in key:
             continue
@@ -56,12 +54,12 @@ def test_eps_golden(nat, name, alpha):
             assert np.array_equal(w, g[base + "_weights"]), (name, base, cap)
 
 
-@pytest.mark.parametrize("alpha", ALPHAS)
+@pytest.mark.parametrize("bits", BITS)
 @pytest.mark.parametrize("name", SETS)
-def test_knn_golden(nat, name, alpha):
+def test_knn_golden(nat, name, bits):
     g = load_golden(name)
     tok = g["tokens"]
-    p = _planes(nat, tok, alpha)
+    p = _planes(nat, tok, bits)
     for key in g.files:
         if not (key.startswith("knn") and key.endswith("_idx")) or "sub" in key or "sim" in key:
             continue
@@ -74,7 +72,7 @@ def test_knn_golden(nat, name, alpha):
 def test_subgraph_rows_are_subset_relative(nat):
     g = load_golden("synth_n515_l20_dups")
     sub = g["sub_idxs"]
-    p = _planes(nat, g["tokens"], 7, rows=sub)
+    p = _planes(nat, g["tokens"], 5, rows=sub)
     indptr, idx, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 2))
     assert np.array_equal(indptr, g["eps2_sub_indptr"]) and np.array_equal(idx, g["eps2_sub_indices"])
     assert np.array_equal(w, g["eps2_sub_weights"])
@@ -104,12 +102,12 @@ def test_dense_kats(nat):
         D = max(X.shape[1], Y.shape[1])
         Xp = np.zeros((X.shape[0], D), np.uint8); Xp[:, :X.shape[1]] = X
         Yp = np.zeros((Y.shape[0], D), np.uint8); Yp[:, :Y.shape[1]] = Y
-        for alpha in ALPHAS:
-            out = nat.hamming_dense(_planes(nat, Xp, alpha), _planes(nat, Yp, alpha))
+        for bits in BITS:
+            out = nat.hamming_dense(_planes(nat, Xp, bits), _planes(nat, Yp, bits))
             assert out.dtype == torch.int64 and np.array_equal(out.cpu().numpy(), g[f"r{i}_out"])
     X, Y = g["wide_X"], g["wide_Y"]
-    xp, yp = nat.pack(torch.from_numpy(X)), nat.pack(torch.from_numpy(Y))
-    assert xp.alpha == 8 or yp.alpha == 8
+    xp, yp = nat.pack(torch.from_numpy(X)), nat.pack(torch.from_numpy(Y), bits=8)
+    assert xp.bits == 8
     assert np.array_equal(nat.hamming_dense(xp, yp).cpu().numpy(), g["wide_out"])
     for ob, dt in [(1, torch.uint8), (4, torch.int32)]:
         out = nat.hamming_dense(xp, yp, out_bytes=ob)
@@ -124,9 +122,9 @@ def test_dense_vs_oracle_all_q(nat):
         Y = X[rng.randint(0, 300, size=70)].copy()
         Y[:, rng.randint(0, L)] = 0
         ref = O.hamming(X.astype(np.int64), Y.astype(np.int64)).numpy()
-        for alpha in ALPHAS:
-            out = nat.hamming_dense(_planes(nat, X, alpha), _planes(nat, Y, alpha))
-            assert np.array_equal(out.cpu().numpy(), ref), (L, alpha)
+        for bits in BITS:
+            out = nat.hamming_dense(_planes(nat, X, bits), _planes(nat, Y, bits))
+            assert np.array_equal(out.cpu().numpy(), ref), (L, bits)
 
 
 def test_engine_vs_oracle_all_q(nat):
@@ -138,12 +136,12 @@ def test_engine_vs_oracle_all_q(nat):
         tok[13] = tok[400]
         ref_e = O.neighbours_to_csr(O.build_graph(tok.astype(np.int64), eps=3))
         ref_k = O.neighbours_to_knn(O.build_graph(tok.astype(np.int64), k=7))
-        for alpha in ALPHAS:
-            p = _planes(nat, tok, alpha)
+        for bits in BITS:
+            p = _planes(nat, tok, bits)
             ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 3))
-            assert np.array_equal(ip, ref_e[0]) and np.array_equal(ix, ref_e[1]) and np.array_equal(w, ref_e[2]), (L, alpha)
+            assert np.array_equal(ip, ref_e[0]) and np.array_equal(ix, ref_e[1]) and np.array_equal(w, ref_e[2]), (L, bits)
             kidx, kd = nat.knn_graph(p, p, 7)
-            assert np.array_equal(kidx.cpu().numpy(), ref_k[0]) and np.array_equal(kd.cpu().numpy(), ref_k[1]), (L, alpha)
+            assert np.array_equal(kidx.cpu().numpy(), ref_k[0]) and np.array_equal(kd.cpu().numpy(), ref_k[1]), (L, bits)
 
 
 def test_knn_edge_cases(nat):
@@ -151,7 +149,7 @@ def test_knn_edge_cases(nat):
     rng = np.random.RandomState(9)
     # N smaller than k+1: missing ranks are -1 / 255; identical rows; k at the maximum
     tok = rng.randint(1, 21, size=(5, 12)).astype(np.uint8)
-    p = _planes(nat, tok, 7)
+    p = _planes(nat, tok, 8)
     idx, d = nat.knn_graph(p, p, 8)
     idx, d = idx.cpu().numpy(), d.cpu().numpy()
     ref = O.neighbours_to_knn(O.build_graph(tok.astype(np.int64), k=8))
@@ -170,7 +168,7 @@ def test_eps_float_thresholds_and_comparators(nat):
     from oracle import prograph_oracle as O
     g = load_golden("synth_n515_l20_dups")
     tok = g["tokens"]
-    p = _planes(nat, tok, 7)
+    p = _planes(nat, tok, 5)
     for op, code in [(operator.le, nat.CMP_LE), (operator.lt, nat.CMP_LT), (operator.eq, nat.CMP_EQ),
                      (operator.ge, nat.CMP_GE), (operator.gt, nat.CMP_GT)]:
         for eps in (1, 2.5, 3, 19, 20, 21, 300):
@@ -182,7 +180,7 @@ def test_eps_float_thresholds_and_comparators(nat):
 def test_index_flags_and_compaction(nat):
     g = load_golden("ref_synthetic_csv")
     tok = g["tokens"]
-    p = _planes(nat, tok, 7)
+    p = _planes(nat, tok, 5)
     dist, hist, _ = nat.index_flags(p, 0, want_flags=False)
     assert np.array_equal(dist.cpu().numpy(), g["dist_to_seed"][0])
     assert np.array_equal(hist.cpu().numpy(), np.bincount(g["dist_to_seed"][0], minlength=256))
@@ -190,14 +188,13 @@ def test_index_flags_and_compaction(nat):
     assert np.array_equal(nat.compact_flags(fl).cpu().numpy(), g["ix_d3"])
     _, _, fl = nat.index_flags(p, 0, want=[1, 3], want_dist_out=False, want_hist=False)
     assert np.array_equal(nat.compact_flags(fl).cpu().numpy(), g["ix_d13"])
-    pm = np.zeros(16, np.uint8); nm = np.zeros(16, np.uint8)
-    pm[[1, 2]] = 0xFF; nm[[0]] = 0xFF
+    pm, nm = [1, 2], [0]
     for mode, key in [(1, "ix_pos12"), (2, "ix_pos12_and")]:
         _, _, fl = nat.index_flags(p, 0, pos_mode=mode, pos_mask=pm, not_mask=nm, want_dist_out=False, want_hist=False)
         assert np.array_equal(nat.compact_flags(fl).cpu().numpy(), g[key])
     _, _, fl = nat.index_flags(p, 0, want=[2], pos_mode=1, pos_mask=pm, not_mask=nm, want_dist_out=False, want_hist=False)
     assert np.array_equal(nat.compact_flags(fl).cpu().numpy(), g["ix_pos12_d2"])
-    pm[:] = 0; nm[:] = 0; pm[1] = 0xFF; nm[[0, 2]] = 0xFF
+    pm, nm = [1], [0, 2]
     _, _, fl = nat.index_flags(p, int(g["LDC_idx"]), pos_mode=1, pos_mask=pm, not_mask=nm, want_dist_out=False, want_hist=False)
     assert np.array_equal(nat.compact_flags(fl).cpu().numpy(), g["ix_LDC_pos1"])
     # compaction at a size that spans many scan tiles
@@ -209,7 +206,9 @@ def test_index_flags_and_compaction(nat):
 
 def test_pack_flags_and_errors(nat):
     tok = np.array([[1, 2, 200], [3, 4, 5]], dtype=np.int64)
-    assert nat.pack(torch.from_numpy(tok)).alpha == 8
+    assert nat.pack(torch.from_numpy(tok)).bits == 8 and nat.pack(torch.from_numpy(tok[1:])).bits == 5
+    with pytest.raises(ValueError):
+        nat.pack(torch.from_numpy(tok), bits=5)
     with pytest.raises(ValueError):
         nat.pack(torch.from_numpy(np.array([[1, 2, 300]], dtype=np.int64)))
     with pytest.raises(ValueError):
@@ -236,8 +235,8 @@ def test_full_size_properties(nat, cfg):
     from prograph_amd import synth
     N, L, eps, k = (50_000, 32, 2, 16) if cfg == "cfg2" else (200_000, 64, 2, 16)
     tok = synth.clustered_tokens(N, L)
-    p = nat.refine_alpha(nat.pack(torch.from_numpy(tok)), 20)
-    assert p.alpha == 5
+    p = nat.pack(torch.from_numpy(tok))
+    assert p.bits == 5
     indptr, idx, w = nat.eps_graph(p, p, nat.CMP_LE, eps, cap=256)
     kidx, kd = nat.knn_graph(p, p, k)
     torch.cuda.synchronize()

@@ -4,7 +4,7 @@ import numpy as np, torch
 from prograph_amd import _native as nat, synth
 def run(N, L, alpha, mode, iters=5):
     tok = synth.clustered_tokens(N, L)
-    p = nat.pack(torch.from_numpy(tok)); p.alpha = alpha
+    p = nat.pack(torch.from_numpy(tok), bits=alpha)
     cap = 256
     dev = p.buf.device
     si = torch.empty(N*cap, dtype=torch.int32, device=dev); sw = torch.empty(N*cap, dtype=torch.uint8, device=dev); cnt = torch.empty(N, dtype=torch.int32, device=dev)
@@ -19,6 +19,6 @@ def run(N, L, alpha, mode, iters=5):
     print(f"N={N} L={L} alpha={alpha} {mode} wpc={os.environ.get('PG_WAVES_PER_CU','8')}: {t*1e3:.2f} ms  {N*N/t:.3e} pairs/s  alg {N*N*L/t/1e12:.2f} TB/s", flush=True)
 for wpc in sys.argv[1:] or ["8"]:
     os.environ["PG_WAVES_PER_CU"] = wpc
-    for alpha in (5, 7):
+    for alpha in (5, 8):
         run(50000, 32, alpha, "eps"); run(50000, 32, alpha, "knn")
         run(200000, 64, alpha, "eps"); run(200000, 64, alpha, "knn")
