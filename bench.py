@@ -177,6 +177,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # PCIe-inclusive rate (never `value`): host numpy tokens -> HBM, one step, results -> host
+    pcie_ms = None
+    if G == 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tok_dev = torch.from_numpy(tok_host).to(dev)
+        step(False)
+        if wl["mode"] == "knn":
+            _ = out[0].cpu(), out[1].cpu()
+        torch.cuda.synchronize()
+        pcie_ms = (time.perf_counter() - t1) * 1e3
+
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in kern_ev]))
     total_pairs = float(rows_local) * N * G                      # every rank does rows_local x N
     ms_per_step = elapsed / a.steps * 1e3
@@ -213,6 +225,9 @@ def main():
         }
         if wl["mode"] == "eps":
             line["config"]["nnz"] = result.get("nnz")
+        if pcie_ms is not None:
+            line["pcie_inclusive"] = {"ms_per_step": pcie_ms, "value": float(rows_local) * N / (pcie_ms * 1e-3),
+                                      "note": "host tokens H2D + step + results D2H (pageable memory); reported only, not `value`"}
         if G == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tok_host, wl, a.cpu_seconds)
         else:
