@@ -36,9 +36,9 @@ static int cu_count() {
 // waves per CU the all-pairs engine is sized for (PG_WAVES_PER_CU overrides; multiples of 4)
 static int waves_per_cu() {
   const char *e = getenv("PG_WAVES_PER_CU");
-  int w = e ? atoi(e) : 16;
+  int w = e ? atoi(e) : 32;
   if (w < 4) w = 4;
-  if (w > 32) w = 32;
+  if (w > 128) w = 128;
   return (w / 4) * 4;
 }
 
@@ -277,9 +277,12 @@ static const compact_fn kCompact[4] = {pg_launch_compact_g1, pg_launch_compact_g
 static int plan_rows(int64_t nrows, NsqParams *p, int *grid) {
   const int cus = cu_count();
   if (cus <= 0) return fail(PG_E_NODEV, "no HIP device");
+  // 32 waves per CU is the measured sweet spot at N = 200k (finer units balance the tail); a
+  // wave should still own >= 6 rows so that the column stream it re-reads is amortised
   const long long maxWaves = (long long)cus * waves_per_cu();
   long long rpw = (nrows + maxWaves - 1) / maxWaves;
-  if (rpw < 1) rpw = 1;
+  const long long minRows = getenv("PG_WAVES_PER_CU") ? 1 : 6;
+  if (rpw < minRows) rpw = minRows;
   const long long waves = (nrows + rpw - 1) / rpw;
   const long long passes = (rpw + 15) / 16;
   p->rowsPerWave = (int)rpw;

@@ -63,23 +63,20 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 #pragma unroll
     for (int rr = 0; rr < PG_RB; ++rr) { cnt[rr] = 0; thr[rr] = 0xFFFFFFFFu; lst[rr] = 0xFFFFFFFFu; }
 
-    uint4 c[C][Q], cn[C][Q];
-#pragma unroll
-    for (int b = 0; b < C; ++b)
-#pragma unroll
-      for (int q = 0; q < Q; ++q) c[b][q] = colp[(long long)q * p.colNpad + b * 64 + lane];
-
-    for (long long t = 0; t < ntiles; ++t) {
-      // prefetch of the next column tile is unconditional (the last iteration re-reads its
-      // own tile) so that the compiler's waitcnt pass can keep it in flight across the rows
-      const long long tn = (t + 1 < ntiles) ? t + 1 : t;
+    // Two register sets hold the current and the next column tile; the tile loop is unrolled by
+    // two so the sets swap roles instead of being copied (no v_mov per tile), and the prefetch
+    // is unconditional (the last tile re-reads itself) so that hipcc's waitcnt pass leaves it in
+    // flight across the row loop with a counted vmcnt.
+    uint4 ca[C][Q], cb[C][Q];
+    auto load_tile = [&](uint4 (&dst)[C][Q], long long t) {
+      const long long tt = t < ntiles ? t : ntiles - 1;
 #pragma unroll
       for (int b = 0; b < C; ++b)
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
-          cn[b][q] = colp[(long long)q * p.colNpad + tn * (64 * C) + b * 64 + lane];
+        for (int q = 0; q < Q; ++q) dst[b][q] = colp[(long long)q * p.colNpad + tt * (64 * C) + b * 64 + lane];
+    };
+    auto sweep_rows = [&](const uint4 (&c)[C][Q], long long t) {
       const u32 col0 = (u32)(t * (64 * C)) + lane;
-
       uint4 r[Q], rn[Q];
 #pragma unroll
       for (int q = 0; q < Q; ++q) r[q] = rows[q];
@@ -102,13 +99,13 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 #pragma unroll
           for (int b = 1; b < C; ++b) dmin = dmin < d[b] ? dmin : d[b];
           const u32 bound = MODE == PG_MODE_EPS ? p.span + 1u : (thr[rr] >> 24);
-          if (__ballot(dmin < bound)) {
+          if (__builtin_amdgcn_ballot_w64(dmin < bound)) {
 #pragma unroll
             for (int b = 0; b < C; ++b) {
               const u32 col = col0 + b * 64;
               if constexpr (MODE == PG_MODE_EPS) {
                 const bool h2 = (d[b] <= p.span) && (col < ncols);
-                const u64 m2 = __ballot(h2);
+                const u64 m2 = __builtin_amdgcn_ballot_w64(h2);
                 if (m2) {
                   const u32 pos = cnt[rr] + mask_rank(m2);
                   if (h2 && pos < p.cap) {
@@ -119,18 +116,20 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
                   cnt[rr] += (u32)__popcll(m2);
                 }
               } else {
-                const u32 key = (d[b] << 24) | col;
-                u64 m = __ballot((d[b] < (thr[rr] >> 24)) && (col < ncols));
-                while (m) {
-                  const int j = __builtin_ctzll(m);
-                  m &= m - 1;
-                  const u32 x = __builtin_amdgcn_readlane(key, j);
-                  if (x < thr[rr]) {
-                    const u32 cur = lst[rr];
-                    const u32 prev = wave_shr1(cur, 0u);
-                    lst[rr] = (cur <= x) ? cur : (prev > x ? prev : x);
-                    thr[rr] = __builtin_amdgcn_readlane(lst[rr], p.k);
-                  }
+                u64 m = __builtin_amdgcn_ballot_w64((d[b] < (thr[rr] >> 24)) && (col < ncols));
+                if (m) {
+                  const u32 key = (d[b] << 24) | col;
+                  do {
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const u32 x = __builtin_amdgcn_readlane(key, j);
+                    if (x < thr[rr]) {
+                      const u32 cur = lst[rr];
+                      const u32 prev = wave_shr1(cur, 0u);
+                      lst[rr] = (cur <= x) ? cur : (prev > x ? prev : x);
+                      thr[rr] = __builtin_amdgcn_readlane(lst[rr], p.k);
+                    }
+                  } while (m);
                 }
               }
             }
@@ -139,10 +138,16 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
           for (int q = 0; q < Q; ++q) r[q] = rn[q];
         }
       }
-#pragma unroll
-      for (int b = 0; b < C; ++b)
-#pragma unroll
-        for (int q = 0; q < Q; ++q) c[b][q] = cn[b][q];
+    };
+
+    load_tile(ca, 0);
+    for (long long t = 0; t < ntiles; t += 2) {
+      load_tile(cb, t + 1);
+      sweep_rows(ca, t);
+      if (t + 1 < ntiles) {
+        load_tile(ca, t + 2);
+        sweep_rows(cb, t + 1);
+      }
     }
 
     // ---- per-row results of this pass ----
