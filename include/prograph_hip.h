@@ -48,6 +48,7 @@ extern "C" {
 #define PG_MAX_L      128          /* bytes per sequence the single-pass kernels take   */
 #define PG_MAX_N_KNN  16777216     /* 2^24                                               */
 #define PG_MAX_K      63           /* k+1 sorted keys live in the 64 lanes of one VGPR   */
+#define PG_LEV_MAX_BAND 8          /* banded Levenshtein keeps 2*8+1 diagonals in registers */
 
 /* bit planes per token: fixed when a matrix is packed, passed to every call that reads it */
 #define PG_BITS_5 5                /* every token <= 31 (20 amino acids + pad): 6 VALU ops / 32 tokens */
@@ -165,6 +166,27 @@ int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int bits,
                    int64_t ref, const uint32_t *want_dist, int pos_mode,
                    const uint32_t *pos_mask, const uint32_t *not_mask,
                    uint8_t *dist_out, uint64_t *hist, uint8_t *flags, void *stream);
+
+/*
+ * Banded Levenshtein kNN — BUILD DEFINED, no reference counterpart (BASELINE.json configs[4],
+ * SURVEY.md §8 row a9; parity unpinned).  d(a,b) = min(edit_distance(a,b), band+1) over the
+ * non-zero prefixes of zero-right-padded uint8 token rows (tokens 1..31); neighbours ordered by
+ * (d, column), rank 0 dropped, ranks 1..k written (missing ranks: idx -1, dist 255).
+ *   pg_lev_profile     tokens (n,l) row-major uint8 -> bag profiles (3*npad*16 bytes) + lens[n];
+ *                      flags[0] = 1 if a token > 31 or an interior zero was seen
+ *   pg_lev_candidates  all-pairs necessary-condition filter max(SAD, 2|dlen|) <= 2*band into
+ *                      per-row candidate slots (ascending columns, exact counts[] even past cap;
+ *                      the caller re-runs with a larger cap when max(counts) > cap)
+ *   pg_lev_knn         exact banded DP per candidate + canonical kNN selection
+ */
+int pg_lev_profile(const uint8_t *tokens, int64_t n, int l, int64_t ld, void *profiles,
+                   int64_t npad, int32_t *lens, uint32_t *flags, void *stream);
+int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row0, int64_t nrows,
+                      int band, int cap, int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts,
+                      void *stream);
+int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const int32_t *lens,
+               int64_t row0, int64_t nrows, int band, int k, int cap, const int32_t *slot_idx,
+               const uint32_t *counts, int32_t *idx_out, uint8_t *dist_out, void *stream);
 
 /*
  * pg_compact_flags — ascending indices of the non-zero flags (np.where(...)[0]).

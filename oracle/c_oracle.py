@@ -62,3 +62,21 @@ def synth(n, l, seed, members=256):
     out = np.empty((n, l), dtype=np.uint8)
     lib().orc_synth(ctypes.c_int64(n), ctypes.c_int(l), ctypes.c_uint64(seed), ctypes.c_int64(members), _p(out))
     return out
+
+
+def lev_pair(a, b, band):
+    a = np.ascontiguousarray(a, dtype=np.uint8); b = np.ascontiguousarray(b, dtype=np.uint8)
+    la = int(np.argmin(np.append(a, 0) != 0)); lb = int(np.argmin(np.append(b, 0) != 0))
+    f = lib().orc_lev_pair
+    f.restype = ctypes.c_int
+    return int(f(_p(a), ctypes.c_int(la), _p(b), ctypes.c_int(lb), ctypes.c_int(band)))
+
+
+def lev_knn(T, k, band=8, row0=0, nrows=None):
+    T = np.ascontiguousarray(T, dtype=np.uint8)
+    n, l = T.shape
+    nrows = n - row0 if nrows is None else nrows
+    idx = np.empty((nrows, k), dtype=np.int32); d = np.empty((nrows, k), dtype=np.uint8)
+    lib().orc_lev_knn(_p(T), ctypes.c_int64(n), ctypes.c_int(l), ctypes.c_int64(row0), ctypes.c_int64(nrows),
+                      ctypes.c_int(band), ctypes.c_int(k), _p(idx), _p(d))
+    return idx, d

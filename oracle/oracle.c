@@ -103,3 +103,59 @@ void orc_synth(int64_t n, int l, uint64_t seed, int64_t members, uint8_t *out) {
     }
   }
 }
+
+/* ---------------------------------------------------------------------------------------
+ * Banded Levenshtein kNN — BUILD DEFINED (no reference counterpart; parity unpinned).
+ * d(a,b) = min(edit_distance(a,b), band+1) on the non-zero prefixes; plain Wagner–Fischer
+ * restricted to |i-j| <= band (exact whenever the true distance is <= band, > band otherwise),
+ * then the canonical (d, column) order, rank 0 dropped, ranks 1..k.
+ * ------------------------------------------------------------------------------------- */
+static int seq_len(const uint8_t *a, int l) {
+  int n = 0;
+  while (n < l && a[n] != 0) ++n;
+  return n;
+}
+
+int orc_lev_pair(const uint8_t *a, int la, const uint8_t *b, int lb, int band) {
+  const int cap = band + 1, INF = 1 << 20;
+  if (la - lb > band || lb - la > band) return cap;
+  int prev[130], cur[130];
+  for (int j = 0; j <= lb; ++j) prev[j] = j <= band ? j : INF;
+  for (int i = 1; i <= la; ++i) {
+    int lo = i - band < 0 ? 0 : i - band, hi = i + band > lb ? lb : i + band;
+    for (int j = 0; j <= lb; ++j) cur[j] = INF;
+    if (lo == 0) cur[0] = i;
+    for (int j = lo < 1 ? 1 : lo; j <= hi; ++j) {
+      int v = prev[j - 1] + (a[i - 1] != b[j - 1]);
+      if (prev[j] + 1 < v) v = prev[j] + 1;
+      if (cur[j - 1] + 1 < v) v = cur[j - 1] + 1;
+      cur[j] = v;
+    }
+    memcpy(prev, cur, sizeof(int) * (size_t)(lb + 1));
+  }
+  return prev[lb] < cap ? prev[lb] : cap;
+}
+
+void orc_lev_knn(const uint8_t *T, int64_t n, int l, int64_t row0, int64_t nrows, int band, int k,
+                 int32_t *idx, uint8_t *dist) {
+  int *lens = (int *)malloc(sizeof(int) * (size_t)n);
+  for (int64_t i = 0; i < n; ++i) lens[i] = seq_len(T + i * l, l);
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int64_t r = 0; r < nrows; ++r) {
+    const uint8_t *a = T + (row0 + r) * l;
+    int64_t best[65];
+    int nb = 0;
+    for (int64_t c = 0; c < n; ++c) {
+      int64_t key = ((int64_t)orc_lev_pair(a, lens[row0 + r], T + c * l, lens[c], band) << 32) | c;
+      if (nb == k + 1 && key >= best[nb - 1]) continue;
+      int p = nb < k + 1 ? nb++ : nb - 1;
+      while (p > 0 && best[p - 1] > key) { best[p] = best[p - 1]; --p; }
+      best[p] = key;
+    }
+    for (int j = 0; j < k; ++j) {
+      if (j + 1 < nb) { idx[r * k + j] = (int32_t)(best[j + 1] & 0xffffffff); dist[r * k + j] = (uint8_t)(best[j + 1] >> 32); }
+      else { idx[r * k + j] = -1; dist[r * k + j] = 255; }
+    }
+  }
+  free(lens);
+}

@@ -20,13 +20,14 @@ ABI_VERSION = 1
 
 BITS_5, BITS_8 = 5, 8
 CMP_LE, CMP_LT, CMP_EQ, CMP_GE, CMP_GT = 0, 1, 2, 3, 4
-MAX_L, MAX_K, MAX_N_KNN = 128, 63, 1 << 24
+MAX_L, MAX_K, MAX_N_KNN, LEV_MAX_BAND = 128, 63, 1 << 24, 8
 
 # every symbol include/prograph_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
     "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_pack_planes",
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
     "pg_eps_compact", "pg_knn_hamming", "pg_index_flags", "pg_compact_flags",
+    "pg_lev_profile", "pg_lev_candidates", "pg_lev_knn",
 ]
 
 
@@ -83,6 +84,9 @@ def _load():
         lib.pg_knn_hamming.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
         lib.pg_index_flags.argtypes = [_vp, _i64, _i64, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_compact_flags.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
+        lib.pg_lev_profile.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp]
+        lib.pg_lev_candidates.argtypes = [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]
+        lib.pg_lev_knn.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]
         for name in SYMBOLS:
             fn = getattr(lib, name)
             if fn.restype is ctypes.c_int and name not in ("pg_version",):
@@ -317,6 +321,51 @@ def compact_flags(flags):
     scratch = torch.empty(int(L.pg_scan_scratch_bytes(n)), dtype=torch.uint8, device=dev)
     _check(L.pg_compact_flags(_ptr(flags), n, _ptr(out), _ptr(cnt), _ptr(scratch), _stream()), "pg_compact_flags")
     return out[: int(cnt.item())]
+
+
+def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats=False):
+    """
+    Banded (capped) Levenshtein kNN — build defined, BASELINE.json configs[4] (no reference
+    counterpart).  `tokens`: (N, L<=128) uint8, tokens 1..31, zero right-padded.
+    Returns (idx int32 (nrows,k), dist uint8 (nrows,k)): ranks 1..k of the (d, column) order with
+    d = min(edit distance, band+1).
+    """
+    L = lib()
+    dev = device()
+    if not isinstance(tokens, torch.Tensor):
+        tokens = torch.from_numpy(np.ascontiguousarray(np.asarray(tokens)))
+    if tokens.dtype != torch.uint8 or tokens.dim() != 2:
+        raise TypeError("levenshtein_knn expects a 2-D uint8 token matrix")
+    tokens = tokens.to(dev).contiguous()
+    n, l = tokens.shape
+    nrows = n - row0 if nrows is None else int(nrows)
+    np_ = npad(n)
+    prof = torch.empty(3 * np_ * 16, dtype=torch.uint8, device=dev)
+    lens = torch.empty(n, dtype=torch.int32, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    _check(L.pg_lev_profile(_ptr(tokens), n, l, tokens.stride(0), _ptr(prof), np_, _ptr(lens), _ptr(flags), _stream()),
+           "pg_lev_profile")
+    if int(flags.item()):
+        raise ValueError("levenshtein_knn: tokens must be 1..31 with zeros only as right padding")
+    counts = torch.empty(nrows, dtype=torch.int32, device=dev)
+    passes = 0
+    while True:
+        passes += 1
+        slot_idx = torch.empty(nrows * cap, dtype=torch.int32, device=dev)
+        slot_w = torch.empty(nrows * cap, dtype=torch.uint8, device=dev)
+        _check(L.pg_lev_candidates(_ptr(prof), np_, n, row0, nrows, int(band), int(cap), _ptr(slot_idx), _ptr(slot_w),
+                                   _ptr(counts), _stream()), "pg_lev_candidates")
+        mx = int(counts.max().item())
+        if mx <= cap:
+            break
+        cap = ((mx + 63) // 64) * 64          # some row has more candidates than slots: redo with room
+    idx = torch.empty((nrows, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((nrows, k), dtype=torch.uint8, device=dev)
+    _check(L.pg_lev_knn(_ptr(tokens), n, l, tokens.stride(0), _ptr(lens), row0, nrows, int(band), int(k), int(cap),
+                        _ptr(slot_idx), _ptr(counts), _ptr(idx), _ptr(dist), _stream()), "pg_lev_knn")
+    if return_stats:
+        return idx, dist, {"candidates": int(counts.to(torch.int64).sum().item()), "cap": cap, "filter_passes": passes}
+    return idx, dist
 
 
 def device_info():

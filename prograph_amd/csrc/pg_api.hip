@@ -432,6 +432,52 @@ int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int bits,
   return launched((int)hipGetLastError(), "pg_index_kernel");
 }
 
+// ---------------------------------------------------------------------------------------
+// banded Levenshtein kNN (build defined; see pg_lev.hip)
+// ---------------------------------------------------------------------------------------
+int pg_lev_profile(const uint8_t *tokens, int64_t n, int l, int64_t ld, void *profiles, int64_t npad, int32_t *lens,
+                   uint32_t *flags, void *stream) {
+  if (!tokens || !profiles || !lens || !flags || n <= 0 || ld < l) return fail(PG_E_BADARG, "pg_lev_profile: bad argument");
+  if (int rc = check_l(l)) return rc;
+  if (npad < n || npad % 256) return fail(PG_E_BADARG, "pg_lev_profile: npad must be pg_npad(n)");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t), s);
+  if (e != hipSuccess) return hipfail(e, "hipMemsetAsync");
+  return launched(pg_launch_lev_profile(tokens, n, l, ld, (u32 *)profiles, npad, lens, flags, s), "pg_lev_profile_kernel");
+}
+
+int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row0, int64_t nrows, int band, int cap,
+                      int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts, void *stream) {
+  if (!profiles || !slot_idx || !slot_w || !counts || n <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > n || cap < 0)
+    return fail(PG_E_BADARG, "pg_lev_candidates: bad argument");
+  if (band < 0 || band > PG_LEV_MAX_BAND) return fail(PG_E_BADARG, "pg_lev_candidates: band must be in 0..8");
+  if (npad < n || npad % 256) return fail(PG_E_BADARG, "pg_lev_candidates: bad npad");
+  if (n > 0x7fffffffLL) return fail(PG_E_TOOMANY, "n exceeds int32 indices");
+  NsqParams p;
+  memset(&p, 0, sizeof(p));
+  p.rowPlanes = (const uint4 *)profiles; p.rowNpad = npad; p.row0 = row0; p.nrows = nrows;
+  p.colPlanes = (const uint4 *)profiles; p.colNpad = npad; p.ncols = n;
+  p.lo = 0; p.span = 2u * (u32)band;             // keep pairs with max(SAD, 2*|dlen|) <= 2*band, self included
+  p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
+  int grid = 0;
+  if (int rc = plan_rows(nrows, &p, &grid)) return rc;
+  return launched(pg_launch_nsq_bag(p, grid, (hipStream_t)stream), "pg_nsq_kernel(bag)");
+}
+
+int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const int32_t *lens, int64_t row0, int64_t nrows,
+               int band, int k, int cap, const int32_t *slot_idx, const uint32_t *counts, int32_t *idx_out,
+               uint8_t *dist_out, void *stream) {
+  if (!tokens || !lens || !slot_idx || !counts || !idx_out || !dist_out || n <= 0 || nrows <= 0 || row0 < 0 ||
+      row0 + nrows > n || ld < l || cap < 0)
+    return fail(PG_E_BADARG, "pg_lev_knn: bad argument");
+  if (int rc = check_l(l)) return rc;
+  if (band < 0 || band > PG_LEV_MAX_BAND) return fail(PG_E_BADARG, "pg_lev_knn: band must be in 0..8");
+  if (k < 1 || k > PG_MAX_K) return fail(PG_E_BADARG, "pg_lev_knn: k must be in 1..63");
+  if (n > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_lev_knn: n exceeds 2^24");
+  return launched(pg_launch_lev_select(tokens, n, l, ld, lens, row0, nrows, band, k, (u32)cap, slot_idx, counts,
+                                       idx_out, dist_out, (hipStream_t)stream), "pg_lev_select_kernel");
+}
+
 int pg_compact_flags(const uint8_t *flags, int64_t n, int64_t *out_idx, int64_t *out_count, void *scratch,
                      void *stream) {
   if (!flags || !out_idx || !out_count || !scratch || n <= 0) return fail(PG_E_BADARG, "pg_compact_flags: bad argument");

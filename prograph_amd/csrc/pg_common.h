@@ -86,6 +86,34 @@ __device__ __forceinline__ u32 mismatch(const uint4 (&r)[Rec<G, B>::Q], const ui
   return acc;
 }
 
+// Metric policies of the all-pairs engine: record size in 16-byte chunks + the pair function.
+template <int G, int B>
+struct HammingMetric {
+  static constexpr int Q = Rec<G, B>::Q;
+  static __device__ __forceinline__ u32 dist(const uint4 (&r)[Q], const uint4 (&c)[Q], u32 init) {
+    return mismatch<G, B>(r, c, init);
+  }
+};
+
+// Edit-distance LOWER BOUND from the bag-of-symbols profile of a sequence (Levenshtein filter):
+// record = 32 symbol counts (bytes, dwords 0..7) + the length stored in two bytes of dword 8.
+//   sad  = sum_s |cnt_a(s) - cnt_b(s)|   (every edit changes it by at most 2)
+//   len2 = 2 * |len_a - len_b|           (every edit changes the length by at most 1)
+// so   max(sad, len2) <= 2 * d_edit;   9 v_sad_u8 + 1 v_max per pair.
+struct BagMetric {
+  static constexpr int Q = 3;
+  static __device__ __forceinline__ u32 dist(const uint4 (&r)[Q], const uint4 (&c)[Q], u32 init) {
+    u32 rw[12], cw[12];
+    unpack<Q>(r, rw);
+    unpack<Q>(c, cw);
+    u32 s = init;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s = __builtin_amdgcn_sad_u8(rw[i], cw[i], s);
+    const u32 l2 = __builtin_amdgcn_sad_u8(rw[8], cw[8], init);
+    return s > l2 ? s : l2;
+  }
+};
+
 // lane's rank among the set bits of a 64-bit wave mask (exclusive prefix popcount)
 __device__ __forceinline__ u32 mask_rank(u64 m) {
   return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
@@ -137,3 +165,9 @@ struct CompactParams {
   int pg_launch_dense_g##G(int bits, const DenseParams &p, hipStream_t s);                    \
   int pg_launch_compact_g##G(int bits, const CompactParams &p, hipStream_t s);
 PG_DECL_G(1) PG_DECL_G(2) PG_DECL_G(3) PG_DECL_G(4)
+int pg_launch_nsq_bag(const NsqParams &p, int grid, hipStream_t s);   // pg_lev.hip
+int pg_launch_lev_profile(const unsigned char *tok, long long n, int l, long long ld, u32 *prof, long long npad,
+                          int *lens, u32 *flags, hipStream_t s);
+int pg_launch_lev_select(const unsigned char *tok, long long n, int l, long long ld, const int *lens, long long row0,
+                         long long nrows, int band, int k, u32 cap, const int *slotIdx, const u32 *counts,
+                         int *knnIdx, unsigned char *knnDist, hipStream_t s);

@@ -23,9 +23,9 @@
 #pragma once
 #include "pg_common.h"
 
-template <int G, int B, int C, int MODE>
+template <class M, int C, int MODE>
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p) {
-  constexpr int Q = Rec<G, B>::Q;
+  constexpr int Q = M::Q;
   __shared__ uint4 rowbuf[PG_WG_WAVES][PG_RB][Q];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
           //      candidate beats the current (k+1)-th key iff its distance is strictly smaller.
           u32 d[C];
 #pragma unroll
-          for (int b = 0; b < C; ++b) d[b] = mismatch<G, B>(r, c[b], bias);
+          for (int b = 0; b < C; ++b) d[b] = M::dist(r, c[b], bias);
           u32 dmin = d[0];
 #pragma unroll
           for (int b = 1; b < C; ++b) dmin = dmin < d[b] ? dmin : d[b];

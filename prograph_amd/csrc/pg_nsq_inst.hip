@@ -17,7 +17,7 @@ struct Cols {
 
 template <int B, int MODE>
 static int launch_nsq(const NsqParams &p, int grid, hipStream_t s) {
-  pg_nsq_kernel<PG_G, B, Cols<B>::C, MODE><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+  pg_nsq_kernel<HammingMetric<PG_G, B>, Cols<B>::C, MODE><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
   return (int)hipGetLastError();
 }
 

@@ -265,3 +265,50 @@ def test_full_size_properties(nat, cfg):
         assert np.array_equal(w[indptr[r]:indptr[r + 1]], d[cols])
         order = np.argsort(d, kind="stable")[1:k + 1]
         assert np.array_equal(kidx[r], order) and np.array_equal(kd[r], d[order])
+
+
+def test_levenshtein_knn_vs_oracle(nat):
+    """Build-defined banded Levenshtein kNN (no reference counterpart: parity unpinned) against the
+    C oracle's plain banded Wagner–Fischer, incl. empty rows, duplicates, bands < 8 and the
+    candidate-slot overflow re-run."""
+    from oracle import c_oracle as C
+    from oracle import prograph_oracle as O
+    from prograph_amd import synth
+    tok, lens = synth.clustered_varlen_tokens(1500, Lmax=128, Lmin=96, seed=31, members=128)
+    tok[7] = tok[900]
+    tok[11] = 0                                    # an empty sequence
+    tok[12, 5:] = 0                                # a very short one
+    for band, k in [(8, 8), (3, 5), (8, 20)]:
+        idx, d, st = nat.levenshtein_knn(torch.from_numpy(tok), k, band=band, return_stats=True)
+        ridx, rd = C.lev_knn(tok, k, band=band)
+        assert np.array_equal(d.cpu().numpy(), rd), (band, k)
+        assert np.array_equal(idx.cpu().numpy(), ridx), (band, k)
+    idx, d, st = nat.levenshtein_knn(torch.from_numpy(tok), 8, band=8, cap=64, return_stats=True)
+    assert st["filter_passes"] == 2 and np.array_equal(idx.cpu().numpy(), C.lev_knn(tok, 8, band=8)[0])
+    # the C oracle's banded DP agrees with the Python definition and with unbanded Wagner–Fischer
+    rng = np.random.RandomState(2)
+    for _ in range(60):
+        i, j = rng.randint(0, 1500, size=2)
+        la, lb = int((tok[i] != 0).sum()), int((tok[j] != 0).sum())
+        full = O.levenshtein_full(tok[i], la, tok[j], lb)
+        assert C.lev_pair(tok[i], tok[j], 8) == min(full, 9) == O.levenshtein_banded(tok[i], la, tok[j], lb, 8)
+    # short sequences, small alphabet: many in-band pairs and ties
+    rng = np.random.RandomState(4)
+    small = np.zeros((400, 24), dtype=np.uint8)
+    for r in range(400):
+        n = rng.randint(0, 25)
+        small[r, :n] = rng.randint(1, 4, size=n)
+    for band in (1, 4, 8):
+        idx, d = nat.levenshtein_knn(torch.from_numpy(small), 12, band=band, cap=1024)
+        ridx, rd = C.lev_knn(small, 12, band=band)
+        assert np.array_equal(d.cpu().numpy(), rd) and np.array_equal(idx.cpu().numpy(), ridx), band
+    # row windows (sharding) and N < k+1
+    idx, d = nat.levenshtein_knn(torch.from_numpy(tok), 8, band=8, row0=700, nrows=333)
+    ridx, rd = C.lev_knn(tok, 8, band=8, row0=700, nrows=333)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
+    idx, d = nat.levenshtein_knn(torch.from_numpy(small[:5]), 8, band=8)
+    ridx, rd = C.lev_knn(small[:5], 8, band=8)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
+    with pytest.raises(ValueError):
+        bad = tok.copy(); bad[3, 2] = 0
+        nat.levenshtein_knn(torch.from_numpy(bad), 8)
