@@ -16,6 +16,7 @@ Workloads (--workload):
   cfg2  N= 50 000, L=32, eps d<=2, full CSR
   cfg4  N=1 000 000, L=64, kNN k=16, row-block sharded: every GPU computes N/8 rows x N columns
         (weak scaling: per-GPU work is fixed, G GPUs cover G/8 of the rows; default for G > 1)
+  cfg5  N=200 000, variable length 96..128, banded Levenshtein (band 8), kNN k=8 — build defined
 """
 import argparse
 import json
@@ -36,6 +37,8 @@ WORKLOADS = {
     "cfg2": dict(N=50_000, L=32, mode="eps", eps=2, k=None, shards=1),
     "cfg3": dict(N=200_000, L=64, mode="knn", eps=None, k=16, shards=1),
     "cfg4": dict(N=1_000_000, L=64, mode="knn", eps=None, k=16, shards=8),
+    # build-defined (no reference counterpart, parity unpinned): variable length 96..128, band 8
+    "cfg5": dict(N=200_000, L=128, mode="lev", eps=None, k=8, shards=1, band=8),
 }
 
 
@@ -62,6 +65,8 @@ def cpu_baseline(tok_host, wl, budget_s):
     t64 = tok_host.astype(np.int64)
     kw = dict(eps=wl["eps"]) if wl["mode"] == "eps" else dict(k=wl["k"])
     t0 = time.perf_counter()
+    if wl["mode"] == "lev":
+        return cpu_baseline_lev(tok_host, wl, budget_s)
     O.build_graph(t64, row_limit=64, **kw)
     pilot = time.perf_counter() - t0
     R = int(max(64, min(4096, (budget_s / max(pilot, 1e-6)) * 64)))
@@ -74,6 +79,24 @@ def cpu_baseline(tok_host, wl, budget_s):
             "sample": f"first {R} rows x all {N} columns of the same token matrix, batch_size=8, "
                       f"{'eps<=%d where/gather' % wl['eps'] if wl['mode'] == 'eps' else 'stable sort, k=%d' % wl['k']}"
                       f" (torch CPU, fp16 staging like prograph.py:726)"}
+
+
+def cpu_baseline_lev(tok_host, wl, budget_s):
+    """No reference code exists for Levenshtein: the baseline is the oracle's C banded
+    Wagner-Fischer + canonical selection (oracle/oracle.c, OpenMP) on a bounded row sample."""
+    from oracle import c_oracle as C
+    N = tok_host.shape[0]
+    t0 = time.perf_counter()
+    C.lev_knn(tok_host, wl["k"], band=wl["band"], row0=0, nrows=8)
+    pilot = time.perf_counter() - t0
+    R = int(max(8, min(2048, (budget_s / max(pilot, 1e-6)) * 8)))
+    t0 = time.perf_counter()
+    C.lev_knn(tok_host, wl["k"], band=wl["band"], row0=0, nrows=R)
+    dt = time.perf_counter() - t0
+    return {"value": R * N / dt, "unit": "sequence-pairs/s", "cores": os.cpu_count(), "kind": "port",
+            "host_cpus": os.cpu_count(), "seconds": round(dt, 2),
+            "sample": f"first {R} rows x all {N} columns, banded Wagner-Fischer (band {wl['band']}) + (d,idx) top-{wl['k']}, C/OpenMP oracle; "
+                      "build-defined workload, no reference implementation exists"}
 
 
 def main():
@@ -109,7 +132,13 @@ def main():
 
     # synthetic input, resident in HBM before the timed region.  With G > 1 every rank owns its
     # row shard and the full matrix is all-gathered inside the step (the path's one collective).
-    if G == 1:
+    if wl["mode"] == "lev":
+        if G != 1:
+            raise SystemExit("cfg5 is a single-GPU workload")
+        tok_host, _ = synth.clustered_varlen_tokens(N, Lmax=L, Lmin=96)
+        tok_dev = torch.from_numpy(tok_host).to(dev)
+        shard_dev = None
+    elif G == 1:
         tok_host = synth.clustered_tokens(N, L)
         tok_dev = torch.from_numpy(tok_host).to(dev)
         shard_dev = None
@@ -121,7 +150,9 @@ def main():
 
     k = wl["k"] or 1
     cap = 256
-    if wl["mode"] == "eps":
+    if wl["mode"] == "lev":
+        pass
+    elif wl["mode"] == "eps":
         slot_idx = torch.empty(rows_local * cap, dtype=torch.int32, device=dev)
         slot_w = torch.empty(rows_local * cap, dtype=torch.uint8, device=dev)
         counts = torch.empty(rows_local, dtype=torch.int32, device=dev)
@@ -131,7 +162,18 @@ def main():
     kern_ev = []
     result = {}
 
+    def step_lev(record):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        idx, d, st = _native.levenshtein_knn(tok_dev, k, band=wl["band"], cap=512, return_stats=True)
+        e1.record()
+        result.update(st)
+        if record:
+            kern_ev.append((e0, e1))
+
     def step(record):
+        if wl["mode"] == "lev":
+            return step_lev(record)
         full = tok_dev if G == 1 else sharded.allgather_tokens(shard_dev, N)
         planes = _native.pack(full, bits=5)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -195,7 +237,7 @@ def main():
     value = total_pairs * a.steps / elapsed
 
     if rank == 0:
-        out_bytes = 5 * k * rows_local if wl["mode"] == "knn" else 8 * (rows_local + 1) + 5 * result.get("nnz", 0)
+        out_bytes = 5 * k * rows_local if wl["mode"] in ("knn", "lev") else 8 * (rows_local + 1) + 5 * result.get("nnz", 0)
         alg_bytes = float(rows_local) * N * L + rows_local * L + out_bytes      # SURVEY.md §8-d, per launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         ops_per_pair = 6 * ((L + 31) // 32) + 0.5                               # 5 bit planes: 6 VALU ops / 32 tokens + shared min/compare
@@ -210,8 +252,10 @@ def main():
             "metric": "sequence-pairs/s", "value": value, "unit": "sequence-pairs/s", "n_gpus": G,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{name}: N={N} L={L} Hamming, " +
-                                   (f"kNN k={k}" if wl["mode"] == "knn" else f"eps d<={wl['eps']} full CSR") +
+            "config": {"workload": f"{name}: N={N} L={L} {'Levenshtein' if wl['mode'] == 'lev' else 'Hamming'}, " +
+                                   (f"kNN k={k}" if wl["mode"] == "knn" else
+                                    f"banded Levenshtein band={wl.get('band')} kNN k={k} (build defined, parity unpinned)" if wl["mode"] == "lev"
+                                    else f"eps d<={wl['eps']} full CSR") +
                                    (f", row-block sharded, {rows_local} rows/GPU x {N} columns, RCCL all-gather in step" if G > 1 or wl["shards"] > 1 else ""),
                        "N": N, "L": L, "rows_per_gpu": rows_local, "alphabet": "5-bit tokens 1..20",
                        "parallelism": f"rowblock{G}"},
@@ -225,6 +269,12 @@ def main():
         }
         if wl["mode"] == "eps":
             line["config"]["nnz"] = result.get("nnz")
+        if wl["mode"] == "lev":
+            line["config"].update({"candidates": result.get("candidates"), "filter_passes": result.get("filter_passes")})
+            line["roofline"]["kernel"] = "pg_lev_* (profile + bag filter pg_nsq_kernel<BagMetric> + pg_lev_select_kernel)"
+            line["roofline"]["note"] = ("kernel_ms spans the three Levenshtein launches; algorithmic bytes = L per ordered pair as for "
+                                        "Hamming; the path is VALU bound (10 ops/pair filter + 4 ops/DP cell on candidates)")
+            line["roofline"]["valu_frac"] = None
         if pcie_ms is not None:
             line["pcie_inclusive"] = {"ms_per_step": pcie_ms, "value": float(rows_local) * N / (pcie_ms * 1e-3),
                                       "note": "host tokens H2D + step + results D2H (pageable memory); reported only, not `value`"}

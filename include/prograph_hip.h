@@ -189,6 +189,17 @@ int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const int32_
                const uint32_t *counts, int32_t *idx_out, uint8_t *dist_out, void *stream);
 
 /*
+ * pg_csr_row_stats — per-row reductions over a CSR graph for the analytics that consume the
+ * `Neighbours` column (prograph/prograph.py:797-946: degree, dirichlet, local_variance):
+ *   deg[r] = sum_j w_rj,  sum_f[r] = sum_j f[col_j],  sum_wf[r] = sum_j w_rj * f[col_j]
+ * weights: uint8 distances OR float32 (exactly one non-NULL; both NULL = boolean weights 1);
+ * f = per-node values (double[ncols]); any output may be NULL.
+ */
+int pg_csr_row_stats(const int64_t *indptr, const int32_t *indices, const uint8_t *weights_u8,
+                     const float *weights_f32, int64_t nrows, const double *f, double *deg,
+                     double *sum_f, double *sum_wf, void *stream);
+
+/*
  * pg_compact_flags — ascending indices of the non-zero flags (np.where(...)[0]).
  *   out_idx int64[n] (worst case), out_count int64[1]; scratch: pg_scan_scratch_bytes(n)
  */

@@ -27,7 +27,7 @@ SYMBOLS = [
     "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_pack_planes",
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
     "pg_eps_compact", "pg_knn_hamming", "pg_index_flags", "pg_compact_flags",
-    "pg_lev_profile", "pg_lev_candidates", "pg_lev_knn",
+    "pg_lev_profile", "pg_lev_candidates", "pg_lev_knn", "pg_csr_row_stats",
 ]
 
 
@@ -84,6 +84,7 @@ def _load():
         lib.pg_knn_hamming.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
         lib.pg_index_flags.argtypes = [_vp, _i64, _i64, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_compact_flags.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
+        lib.pg_csr_row_stats.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]
         lib.pg_lev_profile.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp]
         lib.pg_lev_candidates.argtypes = [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]
         lib.pg_lev_knn.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]
@@ -366,6 +367,22 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
     if return_stats:
         return idx, dist, {"candidates": int(counts.to(torch.int64).sum().item()), "cap": cap, "filter_passes": passes}
     return idx, dist
+
+
+def csr_row_stats(indptr, indices, weights, f=None, want=("deg",)):
+    """Per-row reductions over a device CSR (see pg_csr_row_stats).  `weights`: uint8 or float32
+    device tensor or None (boolean).  Returns a dict of float64 device tensors."""
+    nrows = indptr.numel() - 1
+    dev = indptr.device
+    out = {k: torch.empty(nrows, dtype=torch.float64, device=dev) for k in want}
+    w8 = weights if (weights is not None and weights.dtype == torch.uint8) else None
+    wf = weights if (weights is not None and weights.dtype == torch.float32) else None
+    if weights is not None and w8 is None and wf is None:
+        raise TypeError("weights must be uint8 or float32")
+    fd = None if f is None else f.to(device=dev, dtype=torch.float64).contiguous()
+    _check(lib().pg_csr_row_stats(_ptr(indptr), _ptr(indices), _ptr(w8), _ptr(wf), nrows, _ptr(fd), _ptr(out.get("deg")),
+                                  _ptr(out.get("sum_f")), _ptr(out.get("sum_wf")), _stream()), "pg_csr_row_stats")
+    return out
 
 
 def device_info():

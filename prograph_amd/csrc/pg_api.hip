@@ -230,6 +230,43 @@ __global__ __launch_bounds__(256) void pg_index_kernel(const u32 *__restrict__ p
 }
 
 // =======================================================================================
+// CSR consumers: per-row reductions the graph analytics need
+//   deg[r]  = sum_j w_rj            (degree, prograph/prograph.py:797-822)
+//   sf[r]   = sum_j f[col_j]        (local_variance, :924-946:  mean_j (f_r - f_j) = f_r - sf/cnt)
+//   swf[r]  = sum_j w_rj f[col_j]   (dirichlet, :899-922:  f^T L f = sum_r f_r (deg_r f_r - swf_r))
+// one wave per row, coalesced reads of the row's slice, DPP/shuffle tree reduction.
+// =======================================================================================
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void pg_csr_row_stats_kernel(const long long *__restrict__ indptr,
+                                                               const int *__restrict__ indices,
+                                                               const unsigned char *__restrict__ w8,
+                                                               const float *__restrict__ wf, long long nrows,
+                                                               const double *__restrict__ f, double *deg, double *sf,
+                                                               double *swf) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const long long a = indptr[row], b = indptr[row + 1];
+  double d = 0, s1 = 0, s2 = 0;
+  for (long long e = a + lane; e < b; e += 64) {
+    const double w = w8 ? (double)w8[e] : (wf ? (double)wf[e] : 1.0);
+    const double fj = f ? f[indices[e]] : 0.0;
+    d += w; s1 += fj; s2 += w * fj;
+  }
+  d = wave_sum(d); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) {
+    if (deg) deg[row] = d;
+    if (sf) sf[row] = s1;
+    if (swf) swf[row] = s2;
+  }
+}
+
+// =======================================================================================
 // host side of the ABI
 // =======================================================================================
 static int check_l(int l) {
@@ -476,6 +513,15 @@ int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const int32_
   if (n > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_lev_knn: n exceeds 2^24");
   return launched(pg_launch_lev_select(tokens, n, l, ld, lens, row0, nrows, band, k, (u32)cap, slot_idx, counts,
                                        idx_out, dist_out, (hipStream_t)stream), "pg_lev_select_kernel");
+}
+
+int pg_csr_row_stats(const int64_t *indptr, const int32_t *indices, const uint8_t *weights_u8, const float *weights_f32,
+                     int64_t nrows, const double *f, double *deg, double *sum_f, double *sum_wf, void *stream) {
+  if (!indptr || !indices || nrows <= 0) return fail(PG_E_BADARG, "pg_csr_row_stats: bad argument");
+  if ((sum_f || sum_wf) && !f) return fail(PG_E_BADARG, "pg_csr_row_stats: node values required");
+  pg_csr_row_stats_kernel<<<dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
+      (const long long *)indptr, indices, weights_u8, weights_f32, nrows, f, deg, sum_f, sum_wf);
+  return launched((int)hipGetLastError(), "pg_csr_row_stats_kernel");
 }
 
 int pg_compact_flags(const uint8_t *flags, int64_t n, int64_t *out_idx, int64_t *out_count, void *scratch,

@@ -10,6 +10,8 @@ zero-copy views into two host arrays.
 import numpy as np
 import torch
 
+from . import _native
+
 
 class CSRGraph:
     """epsilon-neighbourhood graph: indptr int64 [n+1], indices int32 [nnz], weights uint8|float32 [nnz]."""
@@ -46,17 +48,41 @@ class CSRGraph:
             out.append((idx[a:b], w[a:b]) if b > a else (np.array([], dtype=int), np.array([], dtype=int)))
         return out
 
+    def _w(self, boolean_weights):
+        if boolean_weights:
+            return None
+        if self.similarity:
+            return (1 / (1 + self.weights.to(torch.int64))).to(torch.float32)
+        return self.weights
+
+    def row_stats(self, f=None, boolean_weights=False, want=("deg",)):
+        """Device reductions per row (pg_csr_row_stats): deg = sum w, sum_f = sum f[col], sum_wf = sum w f[col]."""
+        return _native.csr_row_stats(self.indptr, self.indices, self._w(boolean_weights), f=f, want=want)
+
     def degree(self, boolean_weights=False):
         """Out-degree per row as float32 (prograph.py:797-822) without touching Python tuples."""
-        counts = (self.indptr[1:] - self.indptr[:-1])
         if boolean_weights:
-            return counts.to(torch.float32).cpu().numpy()
-        if self.similarity:
-            w = (1 / (1 + self.weights.to(torch.int64))).to(torch.float32)
-        else:
-            w = self.weights.to(torch.float32)
-        rows = torch.repeat_interleave(torch.arange(self.nrows, device=w.device), counts)
-        return torch.zeros(self.nrows, dtype=torch.float32, device=w.device).index_add_(0, rows, w).cpu().numpy()
+            return (self.indptr[1:] - self.indptr[:-1]).to(torch.float32).cpu().numpy()
+        return self.row_stats(want=("deg",))["deg"].to(torch.float32).cpu().numpy()
+
+    def dirichlet(self, f, boolean_weights=False):
+        """f^T L f with L = D_out - A (prograph.py:874-922), f = per-node values of the ROWS' nodes
+        (square graph: nrows == ncols)."""
+        fd = torch.as_tensor(np.asarray(f, dtype=np.float64).reshape(-1), device=self.indptr.device)
+        st = self.row_stats(f=fd, boolean_weights=boolean_weights, want=("deg", "sum_wf"))
+        fr = fd[self.row0:self.row0 + self.nrows]
+        # the reference keeps the degree in float32 (prograph.py:815) before it enters the Laplacian
+        deg = st["deg"].to(torch.float32).to(torch.float64)
+        return float((fr * (deg * fr - st["sum_wf"])).sum().item())
+
+    def local_variance(self, f):
+        """mean_j (f_r - f_j) over the row's neighbours (prograph.py:924-946); NaN for empty rows."""
+        fd = torch.as_tensor(np.asarray(f, dtype=np.float64).reshape(-1), device=self.indptr.device)
+        st = self.row_stats(f=fd, boolean_weights=True, want=("sum_f",))
+        cnt = (self.indptr[1:] - self.indptr[:-1]).to(torch.float64)
+        fr = fd[self.row0:self.row0 + self.nrows]
+        out = torch.where(cnt > 0, fr - st["sum_f"] / cnt.clamp(min=1), torch.full_like(fr, float("nan")))
+        return out.cpu().numpy()
 
     def coords(self, boolean_weights=False):
         """(I, J, V) of prograph.py:824-857 straight from CSR."""
@@ -88,3 +114,12 @@ class KNNGraph:
     def to_tuples(self):
         idx, w = self.host()
         return list(zip(list(idx), list(w)))
+
+    def as_csr(self):
+        """The same graph as a CSRGraph view (k entries per row; ranks beyond N-1 do not exist)."""
+        kk = min(self.idx.shape[1], max(self.ncols - 1, 0))
+        n = self.nrows
+        indptr = torch.arange(0, n * kk + 1, kk, dtype=torch.int64, device=self.idx.device) if kk else \
+            torch.zeros(n + 1, dtype=torch.int64, device=self.idx.device)
+        return CSRGraph(indptr, self.idx[:, :kk].reshape(-1).contiguous(), self.dist[:, :kk].reshape(-1).contiguous(),
+                        self.ncols, similarity=self.similarity, row0=self.row0)

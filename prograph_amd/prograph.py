@@ -360,14 +360,16 @@ class Prograph:
     # ------------------------------------------------------------------ graph construction
     def build_graph(self, idxs=None, batch_size=8, eps=None, k=None, weighted=False, similarity=False,
                     representation="Tokenized", distance=hamming, comp=operator.le, output="tuples", cap=256,
-                    _keep=None):
+                    store=None, _keep=None):
         """
         epsilon-neighbourhood (`eps`) or kNN (`k`) graph over all pairwise distances
         (reference :656-765).  Returns the reference's list of N `(indices, weights)` tuples;
         `output="csr"` returns the device-resident `CSRGraph` / `KNNGraph` instead (no per-row
         Python objects — what large N wants).  `batch_size` is accepted for compatibility: the
         HIP path tiles the pair space itself.  `cap` = slot capacity per row of the fused pass
-        (rows with more matches are recomputed exactly, so it only affects speed).
+        (rows with more matches are recomputed exactly, so it only affects speed).  `store="Name"`
+        also assigns the result to `self.graph["Name"]` and keeps the device CSR, so that `degree`,
+        `dirichlet`, `local_variance`, `adjacency` on that name run from the CSR on the GPU.
         """
         if operator.xor(bool(eps), bool(k)) is False:
             raise ValueError("Epsilon or K must be provided, but both cannot be as they are different methods of graph construction.")
@@ -394,6 +396,9 @@ class Prograph:
         else:
             idx, dist = _native.knn_graph(planes, planes, k)
             g = KNNGraph(idx, dist, planes.n, similarity=similarity)
+        if store is not None and idxs is None:
+            self.graph[store] = g.to_tuples()
+            _keep = store
         if _keep is not None and idxs is None:
             self.csr_graphs[_keep] = g
         return g if output == "csr" else g.to_tuples()
@@ -430,6 +435,21 @@ class Prograph:
         return list(zip(flatten(edges), flatten(weights)))
 
     # ------------------------------------------------------------------ consumers of the graph column
+    def _device_graph(self, graph):
+        """The device-resident CSR of a graph column built by this object, if it still matches the
+        column (a user may have overwritten `self.graph[name]` with something else)."""
+        g = self.csr_graphs.get(graph)
+        if g is None or graph not in self.graph:
+            return None
+        g = g.as_csr() if isinstance(g, KNNGraph) else g
+        col = self.graph[graph]
+        if len(col) != g.nrows or g.nrows != g.ncols:
+            return None
+        for r in (0, g.nrows - 1):
+            if len(col.iloc[r][0]) != int(g.indptr[r + 1] - g.indptr[r]):
+                return None
+        return g
+
     def _column_csr(self, graph):
         """(indptr, indices, weights) numpy arrays of a Neighbours-style column."""
         col = self(graph)
@@ -440,6 +460,9 @@ class Prograph:
         return indptr, np.concatenate([e[0] for e in col]), np.concatenate([e[1] for e in col])
 
     def degree(self, graph="Neighbours", boolean_weights=False):
+        g = self._device_graph(graph)
+        if g is not None:
+            return g.degree(boolean_weights)
         indptr, _, w = self._column_csr(graph)
         if boolean_weights:
             return np.diff(indptr).astype(np.float32)
@@ -449,6 +472,9 @@ class Prograph:
         return deg
 
     def get_neighbour_coords(self, graph="Neighbours", boolean_weights=False):
+        g = self._device_graph(graph)
+        if g is not None:
+            return g.coords(boolean_weights)
         indptr, J, w = self._column_csr(graph)
         I = np.repeat(np.arange(len(self), dtype=int), np.diff(indptr))
         if boolean_weights:
@@ -477,6 +503,9 @@ class Prograph:
         fitness = self("Fitness").to_numpy().reshape(-1, 1)
         if scaler is not None:
             fitness = scaler().fit_transform(fitness)
+        g = self._device_graph(graph) if mode == "outdegree" else None
+        if g is not None:
+            return np.array([[g.dirichlet(fitness, boolean_weights)]])
         L = self.laplacian(graph=graph, boolean_weights=boolean_weights, mode=mode)
         return fitness.T @ L @ fitness
 
@@ -484,6 +513,9 @@ class Prograph:
         if scaler is _DEFAULT_SCALER:
             from sklearn.preprocessing import MinMaxScaler as scaler
         f = scaler().fit_transform(self("Fitness").to_numpy().reshape(-1, 1)).reshape(-1)
+        g = self._device_graph(graph)
+        if g is not None:
+            return g.local_variance(f)
         indptr, J, _ = self._column_csr(graph)
         out = np.full(len(self), np.nan)
         rows = np.repeat(np.arange(len(self)), np.diff(indptr))

@@ -65,38 +65,48 @@ def clustered_tokens(N, L, seed=DEFAULT_SEED, members=256, row0=0, nrows=None):
     return tok
 
 
-def clustered_varlen_tokens(N, Lmax=128, Lmin=96, seed=DEFAULT_SEED, members=256):
+def clustered_varlen_tokens(N, Lmax=128, Lmin=96, seed=DEFAULT_SEED, members=256, row0=0, nrows=None):
     """
     Variable-length clustered rows for the banded Levenshtein configuration
     (BASELINE.json configs[4]; build defined): cluster
     centres of length Lmin..Lmax, each member takes 1..3 edits drawn from
-    {substitute, insert, delete}; rows are right padded with 0 to Lmax.
-    Returns (tokens (N, Lmax) uint8, lengths (N,) int32).
+    {substitute, insert, delete} applied in order; rows are right padded with 0 to Lmax.
+    Edit t of row i: kind = h(5, 8i+t) % 3, position = h(2, 8i+t) % current_length,
+    token = 1 + h(3, 8i+t) % 20; an insert into a full row / a delete from a 1-token row is a no-op.
+    Returns (tokens (nrows, Lmax) uint8, lengths (nrows,) int32); `row0`/`nrows` select a shard.
     """
     N = int(N)
+    nrows = N - row0 if nrows is None else int(nrows)
     n_centres = max(1, N // members)
     cj = np.arange(n_centres * Lmax, dtype=np.uint64)
     centres = (1 + h(seed, 0, cj) % np.uint64(20)).astype(np.uint8).reshape(n_centres, Lmax)
     clen = (Lmin + h(seed, 4, np.arange(n_centres, dtype=np.uint64)) % np.uint64(Lmax - Lmin + 1)).astype(np.int64)
-    out = np.zeros((N, Lmax), dtype=np.uint8)
-    lens = np.zeros(N, dtype=np.int32)
-    for i in range(N):
-        c = i % n_centres
-        s = list(centres[c, : clen[c]])
-        m = 1 + int(h(seed, 1, i)) % 3
-        for t in range(m):
-            kind = int(h(seed, 5, 8 * i + t)) % 3
-            pos = int(h(seed, 2, 8 * i + t)) % len(s)
-            tokv = 1 + int(h(seed, 3, 8 * i + t)) % 20
-            if kind == 0:
-                s[pos] = tokv
-            elif kind == 1 and len(s) < Lmax:
-                s.insert(pos, tokv)
-            elif kind == 2 and len(s) > 1:
-                del s[pos]
-        out[i, : len(s)] = s
-        lens[i] = len(s)
-    return out, lens
+    i = np.arange(row0, row0 + nrows, dtype=np.uint64)
+    c = (i % np.uint64(n_centres)).astype(np.int64)
+    lens = clen[c].copy()
+    j = np.arange(Lmax)[None, :]
+    arr = np.where(j < lens[:, None], centres[c], 0).astype(np.uint8)
+    m = (1 + h(seed, 1, i) % np.uint64(3)).astype(np.int64)
+    rows = np.arange(nrows)
+    for t in range(3):
+        act = m > t
+        e = np.uint64(8) * i + np.uint64(t)
+        kind = (h(seed, 5, e) % np.uint64(3)).astype(np.int64)
+        pos = (h(seed, 2, e) % lens.astype(np.uint64)).astype(np.int64)
+        tokv = (1 + h(seed, 3, e) % np.uint64(20)).astype(np.uint8)
+        sub = act & (kind == 0)
+        ins = act & (kind == 1) & (lens < Lmax)
+        dele = act & (kind == 2) & (lens > 1)
+        arr[rows[sub], pos[sub]] = tokv[sub]
+        src = np.broadcast_to(j, arr.shape).copy()
+        src[ins] -= (j > pos[ins, None])
+        src[dele] += (j >= pos[dele, None])
+        padded = np.concatenate([arr, np.zeros((nrows, 1), np.uint8)], axis=1)
+        arr = np.take_along_axis(padded, np.minimum(src, Lmax), axis=1)
+        arr[rows[ins], pos[ins]] = tokv[ins]
+        lens = lens + ins.astype(np.int64) - dele.astype(np.int64)
+        arr[j >= lens[:, None]] = 0
+    return arr, lens.astype(np.int32)
 
 
 AMINO = "ACDEFGHIKLMNPQRSTVWY"

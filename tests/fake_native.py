@@ -111,6 +111,20 @@ def _compact_flags(flags):
     return torch.nonzero(flags).reshape(-1).to(torch.int64)
 
 
+def _csr_row_stats(indptr, indices, weights, f=None, want=("deg",)):
+    ip = indptr.numpy(); ix = indices.numpy().astype(np.int64)
+    w = np.ones(len(ix)) if weights is None else weights.numpy().astype(np.float64)
+    rows = np.repeat(np.arange(len(ip) - 1), np.diff(ip))
+    fv = None if f is None else f.numpy().astype(np.float64)
+    out = {}
+    for key in want:
+        acc = np.zeros(len(ip) - 1)
+        vals = w if key == "deg" else (fv[ix] if key == "sum_f" else w * fv[ix])
+        np.add.at(acc, rows, vals)
+        out[key] = torch.from_numpy(acc)
+    return out
+
+
 def install(monkeypatch):
     monkeypatch.setattr(_native, "device", lambda: torch.device("cpu"))
     monkeypatch.setattr(_native, "pack", _pack)
@@ -119,3 +133,4 @@ def install(monkeypatch):
     monkeypatch.setattr(_native, "knn_graph", _knn_graph)
     monkeypatch.setattr(_native, "index_flags", _index_flags)
     monkeypatch.setattr(_native, "compact_flags", _compact_flags)
+    monkeypatch.setattr(_native, "csr_row_stats", _csr_row_stats)

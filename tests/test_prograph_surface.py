@@ -184,6 +184,28 @@ def test_matrix_and_degree(pgraph):
     L = pgraph.laplacian()
     assert L.shape == (1000, 1000) and abs(L.sum()) < 1e-3
     assert np.isfinite(pgraph.dirichlet()).all() and pgraph.local_variance().shape == (1000,)
+    # device-CSR consumers (pg_csr_row_stats) against the column-based host path of the same graph
+    assert pgraph._device_graph("Neighbours") is not None
+    dev = (pgraph.degree(), pgraph.dirichlet(), pgraph.local_variance(), pgraph.dirichlet(boolean_weights=True))
+    saved, pgraph.csr_graphs = pgraph.csr_graphs, {}
+    host = (pgraph.degree(), pgraph.dirichlet(), pgraph.local_variance(), pgraph.dirichlet(boolean_weights=True))
+    pgraph.csr_graphs = saved
+    assert np.array_equal(dev[0], host[0])
+    assert dev[1].shape == (1, 1) and np.allclose(dev[1], host[1], rtol=1e-9) and np.allclose(dev[3], host[3], rtol=1e-9)
+    assert np.allclose(dev[2], host[2], rtol=1e-9, atol=1e-12)
+    # a kNN graph and an eps graph stored under a name use the device CSR as well
+    pgraph.build_graph(k=5, store="K5")
+    pgraph.build_graph(eps=2, store="E2")
+    for name in ("K5", "E2"):
+        d1, v1, q1 = pgraph.degree(name), pgraph.local_variance(name), pgraph.dirichlet(name)
+        saved, pgraph.csr_graphs = pgraph.csr_graphs, {}
+        d0, v0, q0 = pgraph.degree(name), pgraph.local_variance(name), pgraph.dirichlet(name)
+        pgraph.csr_graphs = saved
+        assert np.array_equal(d1, d0) and np.allclose(v1, v0, rtol=1e-9, atol=1e-12) and np.allclose(q1, q0, rtol=1e-9)
+        A = pgraph.adjacency(name)
+        assert A.shape == (1000, 1000) and A.nnz == len(pgraph.get_neighbour_coords(name)[0])
+    pgraph.graph["E2"] = pgraph.build_graph(eps=1)           # user overwrites the column: cache must not be used
+    assert pgraph._device_graph("E2") is None and np.all(pgraph.degree("E2") == 27)
 
 
 # ---------------------------------------------------------------- build_graph: reference outputs, bit-exact
