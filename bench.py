@@ -114,8 +114,11 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if G > 1:
+    use_dist = G > 1 or os.environ.get("PG_FORCE_DIST") == "1"      # PG_FORCE_DIST: rehearse the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     _native.lib()
 
@@ -133,12 +136,12 @@ def main():
     # synthetic input, resident in HBM before the timed region.  With G > 1 every rank owns its
     # row shard and the full matrix is all-gathered inside the step (the path's one collective).
     if wl["mode"] == "lev":
-        if G != 1:
+        if G != 1 or use_dist:
             raise SystemExit("cfg5 is a single-GPU workload")
         tok_host, _ = synth.clustered_varlen_tokens(N, Lmax=L, Lmin=96)
         tok_dev = torch.from_numpy(tok_host).to(dev)
         shard_dev = None
-    elif G == 1:
+    elif not use_dist:
         tok_host = synth.clustered_tokens(N, L)
         tok_dev = torch.from_numpy(tok_host).to(dev)
         shard_dev = None
@@ -174,7 +177,7 @@ def main():
     def step(record):
         if wl["mode"] == "lev":
             return step_lev(record)
-        full = tok_dev if G == 1 else sharded.allgather_tokens(shard_dev, N)
+        full = tok_dev if not use_dist else sharded.allgather_tokens(shard_dev, N)
         planes = _native.pack(full, bits=5)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -202,7 +205,7 @@ def main():
             kern_ev.append((e0, e1))
 
     def fence():
-        if G > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -214,14 +217,14 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if G > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # PCIe-inclusive rate (never `value`): host numpy tokens -> HBM, one step, results -> host
     pcie_ms = None
-    if G == 1:
+    if not use_dist:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         tok_dev = torch.from_numpy(tok_host).to(dev)
@@ -278,12 +281,12 @@ def main():
         if pcie_ms is not None:
             line["pcie_inclusive"] = {"ms_per_step": pcie_ms, "value": float(rows_local) * N / (pcie_ms * 1e-3),
                                       "note": "host tokens H2D + step + results D2H (pageable memory); reported only, not `value`"}
-        if G == 1 and not a.no_cpu_baseline:
+        if not use_dist and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tok_host, wl, a.cpu_seconds)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if G > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

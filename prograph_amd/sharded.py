@@ -38,7 +38,7 @@ def allgather_tokens(local_tokens, n_total, group=None):
     zero-padded to ceil(n/world) rows for the collective and the tail is dropped afterwards).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return local_tokens[:n_total]
     per = -(-int(n_total) // world)
     L = local_tokens.shape[1]

@@ -312,3 +312,51 @@ def test_levenshtein_knn_vs_oracle(nat):
     with pytest.raises(ValueError):
         bad = tok.copy(); bad[3, 2] = 0
         nat.levenshtein_knn(torch.from_numpy(bad), 8)
+
+
+def test_tiny_and_rectangular_shapes(nat):
+    """N = 1, N = 2, and a query block against a different database (row planes != column planes)."""
+    from oracle import prograph_oracle as O
+    one = np.array([[3, 4, 5, 6]], dtype=np.uint8)
+    p = _planes(nat, one, 5)
+    ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 3))
+    assert list(ip) == [0, 0] and len(ix) == 0
+    idx, d = nat.knn_graph(p, p, 2)
+    assert np.all(idx.cpu().numpy() == -1) and np.all(d.cpu().numpy() == 255)
+    dist, hist, fl = nat.index_flags(p, 0, want=[0])
+    assert dist.cpu().numpy().tolist() == [0] and int(hist[0]) == 1 and nat.compact_flags(fl).cpu().numpy().tolist() == [0]
+    two = np.array([[1, 2, 3], [1, 2, 4]], dtype=np.uint8)
+    p = _planes(nat, two, 8)
+    ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 1))
+    assert list(ip) == [0, 1, 2] and list(ix) == [1, 0] and list(w) == [1, 1]
+    idx, d = nat.knn_graph(p, p, 1)
+    assert idx.cpu().numpy().tolist() == [[1], [0]] and d.cpu().numpy().tolist() == [[1], [1]]
+    # rectangular: 37 query rows against a 1000-row database
+    g = load_golden("synth_n1000_l32")
+    db = g["tokens"]
+    rng = np.random.RandomState(3)
+    q = db[rng.randint(0, 1000, size=37)].copy()
+    q[:, rng.randint(0, 32, size=37) % 32] = 1
+    for bits in BITS:
+        qp, dp = _planes(nat, q, bits), _planes(nat, db, bits)
+        dref = O.hamming(db.astype(np.int64), q.astype(np.int64)).numpy()          # (37, 1000)
+        assert np.array_equal(nat.hamming_dense(dp, qp).cpu().numpy(), dref)
+        ip, ix, w = _csr_np(nat.eps_graph(qp, dp, nat.CMP_LE, 3))
+        mask = (dref <= 3) & (dref > 0)
+        assert np.array_equal(ip, np.concatenate([[0], np.cumsum(mask.sum(1))]))
+        assert np.array_equal(ix, np.nonzero(mask)[1]) and np.array_equal(w, dref[mask])
+        idx, d = nat.knn_graph(qp, dp, 5)
+        order = np.argsort(dref, axis=1, kind="stable")[:, 1:6]
+        assert np.array_equal(idx.cpu().numpy(), order) and np.array_equal(d.cpu().numpy(), np.take_along_axis(dref, order, 1))
+
+
+def test_many_rows_per_wave_and_env_override(nat, monkeypatch):
+    """Force few waves (many passes per wave) and many waves (1 row per wave): same results."""
+    g = load_golden("synth_n2085_l64")
+    p = _planes(nat, g["tokens"], 5)
+    for wpc in ("4", "128"):
+        monkeypatch.setenv("PG_WAVES_PER_CU", wpc)
+        ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 4, cap=32))
+        assert np.array_equal(ip, g["eps4_indptr"]) and np.array_equal(ix, g["eps4_indices"]) and np.array_equal(w, g["eps4_weights"])
+        idx, d = nat.knn_graph(p, p, 16)
+        assert np.array_equal(idx.cpu().numpy(), g["knn16_idx"]) and np.array_equal(d.cpu().numpy(), g["knn16_w"])
