@@ -19,8 +19,8 @@
  *   - no exceptions cross the boundary, no hidden global state.
  *
  * Token storage: bit-sliced records in chunk-major order ("planes").  A sequence of L tokens
- * of `bits` bits each is G = ceil(L/32) groups of `bits` bit-plane dwords: dword g*bits+p has
- * bit j = bit p of token 32g+j (positions past L are 0).  The W = G*bits dwords of a record
+ * of `bits` bits each is G = ceil(L/32) groups of `bits` bit-plane dwords: dword p*G+g (plane
+ * major) has bit j = bit p of token 32g+j (positions past L are 0).  The W = G*bits dwords of a record
  * are split into Q = ceil(W/4) 16-byte chunks (tail dwords zero); chunk q of sequence n lives
  * at byte offset (q*Npad + n)*16, Npad = pg_npad(N) (a multiple of 256, sequences past N are
  * zero).  A 64-lane wavefront that owns 64 consecutive sequences therefore reads one chunk per

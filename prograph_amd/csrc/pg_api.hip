@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
     }
 #pragma unroll
     for (int p = 0; p < B; ++p) {
-      const int w = g * B + p;
+      const int w = p * ng + g;               // plane-major record order
       planes[((long long)(w >> 2) * npad + s) * 4 + (w & 3)] = pl[p];
     }
   }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void pg_index_kernel(const u32 *__restrict__ p
       u32 t = 0;
 #pragma unroll
       for (int p = 0; p < B; ++p) {
-        const int w = g * B + p;
+        const int w = p * ng + g;
         const long long base = (long long)(w >> 2) * npad;
         t |= planes[(base + s) * 4 + (w & 3)] ^ planes[(base + ref) * 4 + (w & 3)];
       }
@@ -310,7 +310,7 @@ static const compact_fn kCompact[4] = {pg_launch_compact_g1, pg_launch_compact_g
 
 // Static, even split of the rows over the resident waves: every row costs the same (one
 // sweep over all columns), so equal row counts are equal work.  Each wave then walks its
-// rows in passes of at most PG_RB=16 rows of nearly equal size.
+// rows in passes of at most PG_RB rows of nearly equal size.
 static int plan_rows(int64_t nrows, NsqParams *p, int *grid) {
   const int cus = cu_count();
   if (cus <= 0) return fail(PG_E_NODEV, "no HIP device");
@@ -321,7 +321,7 @@ static int plan_rows(int64_t nrows, NsqParams *p, int *grid) {
   const long long minRows = getenv("PG_WAVES_PER_CU") ? 1 : 6;
   if (rpw < minRows) rpw = minRows;
   const long long waves = (nrows + rpw - 1) / rpw;
-  const long long passes = (rpw + 15) / 16;
+  const long long passes = (rpw + PG_RB - 1) / PG_RB;
   p->rowsPerWave = (int)rpw;
   p->rowsPerPass = (int)((rpw + passes - 1) / passes);
   *grid = (int)((waves + PG_WG_WAVES - 1) / PG_WG_WAVES);
@@ -384,6 +384,8 @@ static int fill_nsq(NsqParams *p, const void *row_planes, int64_t row_npad, int6
   if (col_npad < ncols || col_npad % 256 || row_npad < row0 + nrows) return fail(PG_E_BADARG, "bad npad");
   if (ncols > 0x7fffffffLL) return fail(PG_E_TOOMANY, "ncols exceeds int32 indices");
   memset(p, 0, sizeof(*p));
+  // plane-0 lower-bound filter: adaptive by default; PG_LB_FILTER=0 disables, =2 forces it on
+  p->filter = getenv("PG_LB_FILTER") ? atoi(getenv("PG_LB_FILTER")) : 1;
   p->rowPlanes = (const uint4 *)row_planes; p->rowNpad = row_npad; p->row0 = row0; p->nrows = nrows;
   p->colPlanes = (const uint4 *)col_planes; p->colNpad = col_npad; p->ncols = ncols;
   return 0;
@@ -397,6 +399,7 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
   if (!slot_idx || !slot_w || !counts || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
     return fail(PG_E_BADARG, "pg_eps_slots: bad argument");
   eps_interval(cmp, eps, &p.lo, &p.span);
+  p.hi1 = (p.lo > 0xFFFFFF00u - 1u) ? 0u : p.lo + p.span + 1u;   // empty interval: nothing can match
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
   int grid = 0;
   if (int rc = plan_rows(nrows, &p, &grid)) return rc;
@@ -428,6 +431,7 @@ int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64
   if (!slot_idx || !slot_w || !counts || !indptr || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
     return fail(PG_E_BADARG, "pg_eps_compact: bad argument");
   eps_interval(cmp, eps, &c.e.lo, &c.e.span);
+  c.e.hi1 = c.e.lo + c.e.span + 1u;
   c.e.cap = (u32)cap;
   c.e.slotIdx = const_cast<int *>(slot_idx);
   c.e.slotW = const_cast<unsigned char *>(slot_w);
@@ -494,7 +498,7 @@ int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row
   memset(&p, 0, sizeof(p));
   p.rowPlanes = (const uint4 *)profiles; p.rowNpad = npad; p.row0 = row0; p.nrows = nrows;
   p.colPlanes = (const uint4 *)profiles; p.colNpad = npad; p.ncols = n;
-  p.lo = 0; p.span = 2u * (u32)band;             // keep pairs with max(SAD, 2*|dlen|) <= 2*band, self included
+  p.lo = 0; p.span = 2u * (u32)band; p.hi1 = p.span + 1u;             // keep pairs with max(SAD, 2*|dlen|) <= 2*band, self included
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
   int grid = 0;
   if (int rc = plan_rows(nrows, &p, &grid)) return rc;

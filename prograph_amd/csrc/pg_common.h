@@ -9,7 +9,7 @@ typedef unsigned long long u64;
 #define PG_WAVE 64
 #define PG_WG_WAVES 4
 #define PG_WG_THREADS (PG_WAVE * PG_WG_WAVES)
-#define PG_RB 16    // rows per wave pass of the all-pairs engine
+#define PG_RB 32    // rows per wave pass of the all-pairs engine (<= 64: per-row state is lane indexed)
 #define PG_RBD 64   // rows per workgroup of the dense kernel
 
 enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1 };
@@ -24,7 +24,9 @@ enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1 };
 // down is fewer instructions per token:
 //
 //   a sequence is stored as G = ceil(L/32) groups of B bit planes; plane p of group g is one
-//   dword whose bit j is bit p of token 32g+j.  Two sequences differ at position 32g+j iff
+//   dword whose bit j is bit p of token 32g+j.  Record order is PLANE MAJOR (dword p*G + g), so
+//   chunk 0 of a record is plane 0 of every group: the lower-bound stage of the engine (below)
+//   touches only that chunk.  Two sequences differ at position 32g+j iff
 //   some plane differs there, so   t = OR_p (a[g][p] ^ b[g][p])   has one bit per mismatching
 //   position and popcount(t) is the group's Hamming distance.  gfx950's v_bitop3_b32 evaluates
 //   (a ^ b) | t in ONE instruction (truth table 0xBE for inputs a=0xF0, b=0xCC, c=0xAA), so a
@@ -64,12 +66,12 @@ __device__ __forceinline__ void unpack(const uint4 (&v)[Q], u32 (&w)[4 * Q]) {
   for (int q = 0; q < Q; ++q) { w[4 * q] = v[q].x; w[4 * q + 1] = v[q].y; w[4 * q + 2] = v[q].z; w[4 * q + 3] = v[q].w; }
 }
 
-// per-position "differs" bitmask of group g
-template <int B>
-__device__ __forceinline__ u32 diff_bits(const u32 *a, const u32 *b) {
-  u32 t = a[0] ^ b[0];
+// per-position "differs" bitmask of group g (record dwords are plane major: p*G + g)
+template <int G, int B>
+__device__ __forceinline__ u32 diff_bits(const u32 *a, const u32 *b, int g) {
+  u32 t = a[g] ^ b[g];
 #pragma unroll
-  for (int p = 1; p < B; ++p) t = __builtin_amdgcn_bitop3_b32(a[p], b[p], t, PG_BITOP_XOR_OR);
+  for (int p = 1; p < B; ++p) t = __builtin_amdgcn_bitop3_b32(a[p * G + g], b[p * G + g], t, PG_BITOP_XOR_OR);
   return t;
 }
 
@@ -82,7 +84,18 @@ __device__ __forceinline__ u32 mismatch(const uint4 (&r)[Rec<G, B>::Q], const ui
   unpack<Q>(c, cw);
   u32 acc = init;
 #pragma unroll
-  for (int g = 0; g < G; ++g) acc += __builtin_popcount(diff_bits<B>(&rw[g * B], &cw[g * B]));
+  for (int g = 0; g < G; ++g) acc += __builtin_popcount(diff_bits<G, B>(rw, cw, g));
+  return acc;
+}
+
+// LOWER BOUND of the Hamming distance from plane 0 alone (chunk 0 of both records): positions
+// whose tokens differ in bit 0 certainly differ.  1 v_xor + 1 v_bcnt per 32 tokens.
+template <int G>
+__device__ __forceinline__ u32 mismatch_lb(const uint4 &r0, const uint4 &c0) {
+  u32 acc = __builtin_popcount(r0.x ^ c0.x);
+  if constexpr (G > 1) acc += __builtin_popcount(r0.y ^ c0.y);
+  if constexpr (G > 2) acc += __builtin_popcount(r0.z ^ c0.z);
+  if constexpr (G > 3) acc += __builtin_popcount(r0.w ^ c0.w);
   return acc;
 }
 
@@ -90,9 +103,11 @@ __device__ __forceinline__ u32 mismatch(const uint4 (&r)[Rec<G, B>::Q], const ui
 template <int G, int B>
 struct HammingMetric {
   static constexpr int Q = Rec<G, B>::Q;
+  static constexpr bool kHasLB = true;
   static __device__ __forceinline__ u32 dist(const uint4 (&r)[Q], const uint4 (&c)[Q], u32 init) {
     return mismatch<G, B>(r, c, init);
   }
+  static __device__ __forceinline__ u32 lower_bound(const uint4 &r0, const uint4 &c0) { return mismatch_lb<G>(r0, c0); }
 };
 
 // Edit-distance LOWER BOUND from the bag-of-symbols profile of a sequence (Levenshtein filter):
@@ -102,6 +117,8 @@ struct HammingMetric {
 // so   max(sad, len2) <= 2 * d_edit;   9 v_sad_u8 + 1 v_max per pair.
 struct BagMetric {
   static constexpr int Q = 3;
+  static constexpr bool kHasLB = false;
+  static __device__ __forceinline__ u32 lower_bound(const uint4 &, const uint4 &) { return 0; }
   static __device__ __forceinline__ u32 dist(const uint4 (&r)[Q], const uint4 (&c)[Q], u32 init) {
     u32 rw[12], cw[12];
     unpack<Q>(r, rw);
@@ -131,8 +148,10 @@ struct NsqParams {
   const uint4 *colPlanes;
   long long colNpad, ncols;
   int rowsPerWave, rowsPerPass;
+  int filter;   // 1 = plane-0 lower-bound filter allowed (adaptive per tile), 0 = always direct
   // eps
   u32 lo, span, cap;
+  u32 hi1;      // lo + span + 1 (saturating): a pair whose lower bound reaches it cannot match
   int *slotIdx;
   unsigned char *slotW;
   u32 *counts;

@@ -22,11 +22,15 @@
 // 32 tokens; the operand matrix is cache resident, see DESIGN.md for the roofline.
 #pragma once
 #include "pg_common.h"
+#include <type_traits>
 
 template <class M, int C, int MODE>
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
-  __shared__ uint4 rowbuf[PG_WG_WAVES][PG_RB][Q];
+  constexpr int LROWS = MODE == PG_MODE_KNN ? PG_RB : 1;
+  __shared__ uint4 rowbuf[PG_WG_WAVES][PG_RB + 3][Q];      // +3: the row prefetch runs up to three past
+  __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
+  __shared__ uint4 bndbuf[PG_WG_WAVES][PG_RB / 4 + 2];     // kNN: per row the current (k+1)-th distance
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
@@ -37,6 +41,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
   const uint4 *__restrict__ colp = p.colPlanes;
   const u32 ncols = (u32)p.ncols;
   const uint4 *rows = &rowbuf[wv][0][0] + opaque_zero();   // broadcast reads, kept "divergent"
+  const uint4 *bnds = &bndbuf[wv][0] + opaque_zero();
+  u32 *bndw = reinterpret_cast<u32 *>(&bndbuf[wv][0]);
   // eps: the bias -lo seeds the popcount accumulator (v_bcnt's addend) from an opaque VGPR, so
   // hipcc cannot re-associate it into an extra v_sub per pair
   const u32 bias = MODE == PG_MODE_EPS ? opaque_vgpr(0u - p.lo) : 0u;
@@ -47,26 +53,29 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 
     // ---- stage this pass's rows into the wave's LDS region (wave private: LDS operations
     // of one wave are processed in order, the fences only pin the compiler) ----
-    for (int e = lane; e < PG_RB * Q; e += 64) {
-      const int rr = e % PG_RB, q = e / PG_RB;
+    for (int e = lane; e < (PG_RB + 3) * Q; e += 64) {
+      const int rr = e % (PG_RB + 3), q = e / (PG_RB + 3);
       uint4 v = make_uint4(0, 0, 0, 0);
       if (rr < nr) v = p.rowPlanes[(long long)q * p.rowNpad + p.row0 + pr0 + rr];
       rowbuf[wv][rr][q] = v;
+    }
+    if constexpr (MODE == PG_MODE_KNN) {
+      for (int rr = 0; rr < nr; ++rr) lstbuf[wv][rr][lane] = 0xFFFFFFFFu;
+      if (lane < PG_RB + 8) bndw[lane] = 255u;               // open lists accept every distance
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    u32 cnt[PG_RB];   // eps: matches so far per row (wave uniform -> SGPRs)
-    u32 thr[PG_RB];   // knn: current (k+1)-th smallest key per row (wave uniform -> SGPRs)
-    u32 lst[PG_RB];   // knn: lane j holds the j-th smallest key of the row seen so far
-#pragma unroll
-    for (int rr = 0; rr < PG_RB; ++rr) { cnt[rr] = 0; thr[rr] = 0xFFFFFFFFu; lst[rr] = 0xFFFFFFFFu; }
+    // Per-row state lives in ONE VGPR each, indexed by lane = row-in-pass and touched with
+    // v_readlane / a lane-select (row index is wave uniform):
+    //   eps: cntv = matches so far;   knn: thrv = current (k+1)-th smallest key (0xFFFFFFFF = open)
+    // The kNN lists themselves sit in LDS and are only visited in the slow path.
+    u32 cntv = 0u, thrv = 0xFFFFFFFFu;
 
     // Two register sets hold the current and the next column tile; the tile loop is unrolled by
-    // two so the sets swap roles instead of being copied (no v_mov per tile), and the prefetch
-    // is unconditional (the last tile re-reads itself) so that hipcc's waitcnt pass leaves it in
-    // flight across the row loop with a counted vmcnt.
+    // two so the sets swap roles instead of being copied, and the prefetch is unconditional (the
+    // last tile re-reads itself) so that the waitcnt pass leaves it in flight across the rows.
     uint4 ca[C][Q], cb[C][Q];
     auto load_tile = [&](uint4 (&dst)[C][Q], long long t) {
       const long long tt = t < ntiles ? t : ntiles - 1;
@@ -75,97 +84,180 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 #pragma unroll
         for (int q = 0; q < Q; ++q) dst[b][q] = colp[(long long)q * p.colNpad + tt * (64 * C) + b * 64 + lane];
     };
-    auto sweep_rows = [&](const uint4 (&c)[C][Q], long long t) {
-      const u32 col0 = (u32)(t * (64 * C)) + lane;
-      uint4 r[Q], rn[Q];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) r[q] = rows[q];
-#pragma unroll
-      for (int rr = 0; rr < PG_RB; ++rr) {
-        if (rr < nr) {
-          // broadcast read of the next row is issued before this row's compares
-          if (rr + 1 < PG_RB) {
-#pragma unroll
-            for (int q = 0; q < Q; ++q) rn[q] = rows[(rr + 1) * Q + q];
+
+    // exact distance of row rr against ONE 64-column sub-tile b + epilogue (slot append / sorted
+    // insertion).  eps: (comp(d, eps) & (d > 0)) is one unsigned range test lo <= d <= lo+span, the
+    // bias -lo rides in the popcount accumulator.  knn: keys are (distance << 24 | column); columns
+    // only grow along the sweep, so a candidate beats the current (k+1)-th key iff its distance is
+    // strictly smaller.
+    auto epilogue = [&](u32 d, u32 col, int rr) {
+      if constexpr (MODE == PG_MODE_EPS) {
+        const bool h2 = (d <= p.span) && (col < ncols);
+        const u64 m2 = __builtin_amdgcn_ballot_w64(h2);
+        if (m2) {
+          const u32 cnt = __builtin_amdgcn_readlane(cntv, rr);
+          const u32 pos = cnt + mask_rank(m2);
+          if (h2 && pos < p.cap) {
+            const long long o = (pr0 + rr) * (long long)p.cap + pos;
+            p.slotIdx[o] = (int)col;
+            p.slotW[o] = (unsigned char)(d + p.lo);
           }
-          // eps: (comp(d, eps) & (d > 0)) is one unsigned range test lo <= d <= lo+span; the
-          //      bias -lo rides in the popcount accumulator.
-          // knn: keys are (distance << 24 | column); columns only grow along the sweep, so a
-          //      candidate beats the current (k+1)-th key iff its distance is strictly smaller.
-          u32 d[C];
+          cntv = (lane == rr) ? cnt + (u32)__popcll(m2) : cntv;
+        }
+      } else {
+        u32 thr = __builtin_amdgcn_readlane(thrv, rr);
+        u64 m = __builtin_amdgcn_ballot_w64((d < (thr >> 24)) && (col < ncols));
+        if (m) {
+          const u32 key = (d << 24) | col;
+          u32 lst = lstbuf[wv][rr][lane];
+          do {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const u32 x = __builtin_amdgcn_readlane(key, j);
+            if (x < thr) {
+              const u32 prev = wave_shr1(lst, 0u);
+              lst = (lst <= x) ? lst : (prev > x ? prev : x);
+              thr = __builtin_amdgcn_readlane(lst, p.k);
+            }
+          } while (m);
+          lstbuf[wv][rr][lane] = lst;
+          thrv = (lane == rr) ? thr : thrv;
+          if (lane == 0) bndw[rr] = thr >> 24;
+        }
+      }
+    };
+
+    // Direct form of one row-step: all C exact distances, one min + compare + branch.  Chunk 0 of
+    // the row arrives prefetched, the remaining chunks are read here (keeping only chunk 0 in the
+    // double buffer holds the kernel at 3 waves per SIMD; buffering whole rows costs a wave).
+    auto row_direct = [&](const uint4 (&c)[C][Q], const uint4 &r0, int rr, u32 col0) {
+      uint4 r[Q];
+      r[0] = r0;
 #pragma unroll
-          for (int b = 0; b < C; ++b) d[b] = M::dist(r, c[b], bias);
-          u32 dmin = d[0];
+      for (int q = 1; q < Q; ++q) r[q] = rows[rr * Q + q];
+      u32 d[C];
 #pragma unroll
-          for (int b = 1; b < C; ++b) dmin = dmin < d[b] ? dmin : d[b];
-          const u32 bound = MODE == PG_MODE_EPS ? p.span + 1u : (thr[rr] >> 24);
-          if (__builtin_amdgcn_ballot_w64(dmin < bound)) {
+      for (int b = 0; b < C; ++b) d[b] = M::dist(r, c[b], bias);
+      u32 dmin = d[0];
 #pragma unroll
-            for (int b = 0; b < C; ++b) {
-              const u32 col = col0 + b * 64;
-              if constexpr (MODE == PG_MODE_EPS) {
-                const bool h2 = (d[b] <= p.span) && (col < ncols);
-                const u64 m2 = __builtin_amdgcn_ballot_w64(h2);
-                if (m2) {
-                  const u32 pos = cnt[rr] + mask_rank(m2);
-                  if (h2 && pos < p.cap) {
-                    const long long o = (pr0 + rr) * (long long)p.cap + pos;
-                    p.slotIdx[o] = (int)col;
-                    p.slotW[o] = (unsigned char)(d[b] + p.lo);
-                  }
-                  cnt[rr] += (u32)__popcll(m2);
-                }
-              } else {
-                u64 m = __builtin_amdgcn_ballot_w64((d[b] < (thr[rr] >> 24)) && (col < ncols));
-                if (m) {
-                  const u32 key = (d[b] << 24) | col;
-                  do {
-                    const int j = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const u32 x = __builtin_amdgcn_readlane(key, j);
-                    if (x < thr[rr]) {
-                      const u32 cur = lst[rr];
-                      const u32 prev = wave_shr1(cur, 0u);
-                      lst[rr] = (cur <= x) ? cur : (prev > x ? prev : x);
-                      thr[rr] = __builtin_amdgcn_readlane(lst[rr], p.k);
-                    }
-                  } while (m);
-                }
+      for (int b = 1; b < C; ++b) dmin = dmin < d[b] ? dmin : d[b];
+      const u32 bound = MODE == PG_MODE_EPS ? p.span + 1u : (__builtin_amdgcn_readlane(thrv, rr) >> 24);
+      if (__builtin_amdgcn_ballot_w64(dmin < bound)) {
+#pragma unroll
+        for (int b = 0; b < C; ++b) epilogue(d[b], col0 + b * 64, rr);
+      }
+    };
+
+    // One tile against the pass's rows, direct form: the row loop is unrolled by two with two
+    // static chunk-0 buffers refilled (broadcast ds_read_b128) right after their last use.  Rows
+    // nr.. exist in the buffer as zeros, so trailing prefetches are harmless.
+    auto sweep_direct = [&](const uint4 (&c)[C][Q], long long t) {
+      const u32 col0 = (u32)(t * (64 * C)) + lane;
+      uint4 ra = rows[0], rb = rows[Q];
+      for (int rr = 0; rr < nr; rr += 2) {
+        row_direct(c, ra, rr, col0);
+        ra = rows[(rr + 2) * Q];
+        if (rr + 1 < nr) row_direct(c, rb, rr + 1, col0);
+        rb = rows[(rr + 3) * Q];
+      }
+    };
+
+    // Filtered form: rows are taken FOUR at a time.  Stage 1 of the four rows (lower bounds from
+    // chunk 0, min over the C sub-tiles, compare with the row's bound) is straight-line code with
+    // four independent dependency chains and no branch; the four wave masks are then examined
+    // with scalar branches, and only rows whose mask is non-zero enter stage 2.  This keeps the
+    // VALU busy at 3 waves per SIMD: the serial tail (ballot -> branch) is paid once per 4 rows.
+    // kNN bounds come from LDS (one broadcast ds_read_b128 = the four rows' current (k+1)-th
+    // distances, written by the slow path), eps uses the constant hi+1.
+    auto sweep_filtered = [&](const uint4 (&c)[C][Q], long long t) -> int {
+      const u32 col0 = (u32)(t * (64 * C)) + lane;
+      int trig = 0;
+      uint4 r4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r4[u] = rows[u * Q];
+      uint4 bnd = make_uint4(p.hi1, p.hi1, p.hi1, p.hi1);
+      if constexpr (MODE == PG_MODE_KNN) bnd = bnds[0];
+      for (int rr = 0; rr < nr; rr += 4) {
+        u64 m[4];
+        const u32 bv[4] = {bnd.x, bnd.y, bnd.z, bnd.w};
+        u32 lb[4][C];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int b = 0; b < C; ++b) lb[u][b] = M::lower_bound(r4[u], c[b][0]);
+          u32 lbmin = lb[u][0];
+#pragma unroll
+          for (int b = 1; b < C; ++b) lbmin = lbmin < lb[u][b] ? lbmin : lb[u][b];
+          m[u] = __builtin_amdgcn_ballot_w64(lbmin < bv[u]);
+        }
+        // next four rows' chunk 0 and bounds (rows of THIS group are not among them)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r4[u] = rows[(rr + 4 + u) * Q];
+        if constexpr (MODE == PG_MODE_KNN) bnd = bnds[(rr >> 2) + 1];
+        if (m[0] | m[1] | m[2] | m[3]) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (m[u] && rr + u < nr) {
+              ++trig;
+              uint4 r[Q];
+#pragma unroll
+              for (int q = 0; q < Q; ++q) r[q] = rows[(rr + u) * Q + q];
+#pragma unroll
+              for (int b = 0; b < C; ++b) {
+                if (__builtin_amdgcn_ballot_w64(lb[u][b] < bv[u])) epilogue(M::dist(r, c[b], bias), col0 + b * 64, rr + u);
               }
             }
           }
-#pragma unroll
-          for (int q = 0; q < Q; ++q) r[q] = rn[q];
         }
       }
+      return trig;
+    };
+    // Adaptive choice: the filter pays while, on average, fewer than ~2/3 of the row-steps need
+    // stage 2; when the data are dense (mutant libraries: almost every pair is near) the direct
+    // form is cheaper.  The decision uses the trigger count of a WINDOW of 16 filtered tiles (single
+    // tiles are all-or-nothing when neighbouring rows share neighbouring columns); after a window
+    // that fails, 48 tiles run direct before the filter is probed again.  Wave uniform throughout.
+    int win_tiles = 0, win_trig = 0, direct_left = 0;
+    auto sweep = [&](const uint4 (&c)[C][Q], long long t) {
+      if constexpr (M::kHasLB) {
+        if (p.filter != 0 && direct_left == 0) {
+          win_trig += sweep_filtered(c, t);
+          if (++win_tiles == 16) {
+            if (p.filter == 1 && win_trig * 3 > nr * 16 * 2) direct_left = 48;   // filter == 2: forced on
+            win_tiles = 0;
+            win_trig = 0;
+          }
+          return;
+        }
+        if (direct_left > 0) --direct_left;
+      }
+      sweep_direct(c, t);
     };
 
     load_tile(ca, 0);
     for (long long t = 0; t < ntiles; t += 2) {
       load_tile(cb, t + 1);
-      sweep_rows(ca, t);
+      sweep(ca, t);
       if (t + 1 < ntiles) {
         load_tile(ca, t + 2);
-        sweep_rows(cb, t + 1);
+        sweep(cb, t + 1);
       }
     }
 
     // ---- per-row results of this pass ----
-#pragma unroll
-    for (int rr = 0; rr < PG_RB; ++rr) {
-      if (rr < nr) {
-        if constexpr (MODE == PG_MODE_EPS) {
-          if (lane == 0) p.counts[pr0 + rr] = cnt[rr];
-        } else {
-          if (lane >= 1 && lane <= p.k) {
-            const u32 key = lst[rr];
-            const long long o = (pr0 + rr) * (long long)p.k + (lane - 1);
-            p.knnIdx[o] = (key == 0xFFFFFFFFu) ? -1 : (int)(key & 0x00FFFFFFu);
-            p.knnDist[o] = (unsigned char)(key >> 24);
-          }
+    if constexpr (MODE == PG_MODE_EPS) {
+      if (lane < nr) p.counts[pr0 + lane] = cntv;
+    } else {
+      for (int rr = 0; rr < nr; ++rr) {
+        if (lane >= 1 && lane <= p.k) {
+          const u32 key = lstbuf[wv][rr][lane];
+          const long long o = (pr0 + rr) * (long long)p.k + (lane - 1);
+          p.knnIdx[o] = (key == 0xFFFFFFFFu) ? -1 : (int)(key & 0x00FFFFFFu);
+          p.knnDist[o] = (unsigned char)(key >> 24);
         }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
 }
