@@ -101,6 +101,11 @@ def cpu_baseline_lev(tok_host, wl, budget_s):
 
 def main():
     a = parse()
+    # stdout must carry exactly ONE JSON line: park fd 1 on stderr while libraries (RCCL prints a
+    # version banner to stdout at communicator creation) run, restore it for the final print
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     G = a.gpus
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -285,7 +290,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(tok_host, wl, a.cpu_seconds)
         else:
             line["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
