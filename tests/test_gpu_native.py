@@ -360,3 +360,38 @@ def test_many_rows_per_wave_and_env_override(nat, monkeypatch):
         assert np.array_equal(ip, g["eps4_indptr"]) and np.array_equal(ix, g["eps4_indices"]) and np.array_equal(w, g["eps4_weights"])
         idx, d = nat.knn_graph(p, p, 16)
         assert np.array_equal(idx.cpu().numpy(), g["knn16_idx"]) and np.array_equal(d.cpu().numpy(), g["knn16_w"])
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_lower_bound_filter_modes_agree(nat, monkeypatch, mode):
+    """PG_LB_FILTER = 0 (direct form only), 1 (adaptive), 2 (two-stage form forced): the plane-0
+    lower-bound stage is exact, so every mode must reproduce the golden vectors — on clustered data
+    (filter mostly skips), on dense data (every row-step triggers) and for all comparators."""
+    monkeypatch.setenv("PG_LB_FILTER", mode)
+    for name in ("synth_n2085_l64", "synth_n515_l20_dups", "ref_synthetic_csv"):
+        g = load_golden(name)
+        for bits in BITS:
+            p = _planes(nat, g["tokens"], bits)
+            for key in g.files:
+                if key.endswith("_indptr") and "sub" not in key and "sim" not in key and "_b5" not in key:
+                    base = key[:-7]
+                    parts = base.split("_")
+                    cmp = {"eq": nat.CMP_EQ, "lt": nat.CMP_LT, "ge": nat.CMP_GE, "gt": nat.CMP_GT}[parts[1]] if len(parts) > 1 else nat.CMP_LE
+                    ip, ix, w = _csr_np(nat.eps_graph(p, p, cmp, int(parts[0][3:]), cap=64))
+                    assert np.array_equal(ip, g[base + "_indptr"]) and np.array_equal(ix, g[base + "_indices"]), (name, base, mode)
+                    assert np.array_equal(w, g[base + "_weights"])
+                if key.startswith("knn") and key.endswith("_idx") and "sub" not in key and "sim" not in key:
+                    k = int(key[3:-4])
+                    idx, d = nat.knn_graph(p, p, k)
+                    assert np.array_equal(idx.cpu().numpy(), g[f"knn{k}_idx"]) and np.array_equal(d.cpu().numpy(), g[f"knn{k}_w"]), (name, k, mode)
+    # a long sweep (many tiles, several adaptive windows) against the C oracle
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    tok = synth.clustered_tokens(30_000, 64, seed=77, members=64)
+    p = _planes(nat, tok, 5)
+    ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 3, cap=128))
+    rip, rix, rw = C.eps_csr(tok, 0, 3)
+    assert np.array_equal(ip, rip) and np.array_equal(ix, rix) and np.array_equal(w, rw)
+    idx, d = nat.knn_graph(p, p, 16)
+    ridx, rd = C.knn(tok, 16)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
