@@ -14,8 +14,11 @@ slots + scan + CSR compaction).  Prints ONE JSON line on rank 0.
 Workloads (--workload):
   cfg3  N=200 000, L=64, kNN k=16        the configuration the target is quoted on (default, G=1)
   cfg2  N= 50 000, L=32, eps d<=2, full CSR
+  cfg3w the weak-scaling series anchored at cfg3 (default for G > 1): a square N_G x N_G problem with
+        N_G = 200 000 * sqrt(G), row-block sharded over G GPUs, so every GPU always evaluates 4.0e10
+        ordered pairs (G=1 is cfg3 itself, G=8 is N=565 688); the all-gather and the pack are in the step
   cfg4  N=1 000 000, L=64, kNN k=16, row-block sharded: every GPU computes N/8 rows x N columns
-        (weak scaling: per-GPU work is fixed, G GPUs cover G/8 of the rows; default for G > 1)
+        (BASELINE.json configs[3]; G GPUs cover G/8 of the rows, G=8 is the full graph)
   cfg5  N=200 000, variable length 96..128, banded Levenshtein (band 8), kNN k=8 — build defined
 """
 import argparse
@@ -36,6 +39,7 @@ VALU_WAVE_INSTR = 256 * 4 * 2.4e9 / 4   # measured: one wave64 integer VALU inst
 WORKLOADS = {
     "cfg2": dict(N=50_000, L=32, mode="eps", eps=2, k=None, shards=1),
     "cfg3": dict(N=200_000, L=64, mode="knn", eps=None, k=16, shards=1),
+    "cfg3w": dict(N=200_000, L=64, mode="knn", eps=None, k=16, shards=1),     # N is scaled by sqrt(G) in main()
     "cfg4": dict(N=1_000_000, L=64, mode="knn", eps=None, k=16, shards=8),
     # build-defined (no reference counterpart, parity unpinned): variable length 96..128, band 8
     "cfg5": dict(N=200_000, L=128, mode="lev", eps=None, k=8, shards=1, band=8),
@@ -127,8 +131,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     _native.lib()
 
-    name = a.workload if a.workload != "auto" else ("cfg3" if G == 1 else "cfg4")
+    name = a.workload if a.workload != "auto" else ("cfg3" if G == 1 else "cfg3w")
     wl = dict(WORKLOADS[name])
+    if name == "cfg3w":
+        # weak scaling: N_G^2 / G = 200000^2 pairs per GPU, N_G a multiple of 8*G (equal row blocks)
+        unit = 8 * G
+        wl["N"] = int(-(-int(round(200_000 * (G ** 0.5))) // unit) * unit)
     N, L = wl["N"], wl["L"]
     if wl["shards"] > 1:
         per = N // wl["shards"]                 # rows per GPU, fixed (weak scaling)

@@ -214,16 +214,17 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     };
     // Adaptive choice: the filter pays while, on average, fewer than ~2/3 of the row-steps need
     // stage 2; when the data are dense (mutant libraries: almost every pair is near) the direct
-    // form is cheaper.  The decision uses the trigger count of a WINDOW of 16 filtered tiles (single
+    // form is cheaper.  The decision uses the trigger count of a WINDOW of 8 filtered tiles (single
     // tiles are all-or-nothing when neighbouring rows share neighbouring columns); after a window
-    // that fails, 48 tiles run direct before the filter is probed again.  Wave uniform throughout.
+    // that fails, 120 tiles run direct before the filter is probed again (probing a dense data set
+    // costs ~2 %).  Wave uniform throughout.
     int win_tiles = 0, win_trig = 0, direct_left = 0;
     auto sweep = [&](const uint4 (&c)[C][Q], long long t) {
       if constexpr (M::kHasLB) {
         if (p.filter != 0 && direct_left == 0) {
           win_trig += sweep_filtered(c, t);
-          if (++win_tiles == 16) {
-            if (p.filter == 1 && win_trig * 3 > nr * 16 * 2) direct_left = 48;   // filter == 2: forced on
+          if (++win_tiles == 8) {
+            if (p.filter == 1 && win_trig * 3 > nr * 8 * 2) direct_left = 120;   // filter == 2: forced on
             win_tiles = 0;
             win_trig = 0;
           }
