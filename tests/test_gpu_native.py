@@ -395,3 +395,36 @@ def test_lower_bound_filter_modes_agree(nat, monkeypatch, mode):
     idx, d = nat.knn_graph(p, p, 16)
     ridx, rd = C.knn(tok, 16)
     assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
+
+
+def test_randomised_shapes_against_c_oracle(nat):
+    """Seeded sweep over shapes that hit every template instance (G = 1..4 groups, 5 / 8 bit planes,
+    C = 4 / 2 / 1 columns per lane), odd N, odd L, tiny and skewed alphabets, every comparator,
+    random eps / k, random row windows — eps CSR, kNN and dense against the C oracle."""
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(20260104)
+    for it in range(40):
+        N = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 256, 257, 700, 1500, 2600]))
+        L = int(rng.randint(1, 129))
+        amax = int(rng.choice([1, 2, 4, 20, 31, 32, 127, 255]))
+        base = rng.randint(0, amax + 1, size=(max(1, N // 40), L))
+        tok = base[rng.randint(0, len(base), size=N)].copy()
+        nmut = rng.randint(0, 4, size=N)
+        for r in range(N):
+            for _ in range(nmut[r]):
+                tok[r, rng.randint(0, L)] = rng.randint(0, amax + 1)
+        tok = tok.astype(np.uint8)
+        bits = 5 if (amax <= 31 and rng.rand() < 0.7) else 8
+        p = _planes(nat, tok, bits)
+        row0 = int(rng.randint(0, N)); nrows = int(rng.randint(1, N - row0 + 1))
+        cmp = int(rng.randint(0, 5)); eps = float(rng.choice([1, 2, 3, 5, 2.5, L, L + 3]))
+        rip, rix, rw = C.eps_csr(tok, cmp, eps, row0=row0, nrows=nrows)
+        ip, ix, w = _csr_np(nat.eps_graph(p, p, cmp, eps, row0=row0, nrows=nrows, cap=int(rng.choice([1, 16, 256]))))
+        assert np.array_equal(ip, rip) and np.array_equal(ix, rix) and np.array_equal(w, rw), (it, N, L, bits, cmp, eps)
+        k = int(rng.choice([1, 2, 7, 16, 33, 63]))
+        ridx, rd = C.knn(tok, k, row0=row0, nrows=nrows)
+        idx, d = nat.knn_graph(p, p, k, row0=row0, nrows=nrows)
+        assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd), (it, N, L, bits, k)
+        if N <= 700:
+            m = min(N, 50)
+            assert np.array_equal(nat.hamming_dense(p, _planes(nat, tok[:m], bits)).cpu().numpy(), C.hamming(tok, tok[:m])), (it, N, L)
