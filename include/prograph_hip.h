@@ -41,11 +41,12 @@ extern "C" {
 
 /* library error codes (negative return values) */
 #define PG_E_BADARG   (-1)   /* NULL pointer, negative size, k out of range ...        */
-#define PG_E_TOOLONG  (-2)   /* L > PG_MAX_L for this entry point                       */
+#define PG_E_TOOLONG  (-2)   /* L > PG_MAX_L (PG_MAX_L_5BIT with 5 bit planes)          */
 #define PG_E_TOOMANY  (-3)   /* N > PG_MAX_N_KNN (24-bit column index in packed keys)   */
 #define PG_E_NODEV    (-4)   /* no HIP device / wrong architecture                      */
 
-#define PG_MAX_L      128          /* bytes per sequence the single-pass kernels take   */
+#define PG_MAX_L      128          /* tokens per sequence, 8 bit planes                  */
+#define PG_MAX_L_5BIT 255          /* tokens per sequence, 5 bit planes (distance fits uint8) */
 #define PG_MAX_N_KNN  16777216     /* 2^24                                               */
 #define PG_MAX_K      63           /* k+1 sorted keys live in the 64 lanes of one VGPR   */
 #define PG_LEV_MAX_BAND 8          /* banded Levenshtein keeps 2*8+1 diagonals in registers */

@@ -20,7 +20,7 @@ ABI_VERSION = 1
 
 BITS_5, BITS_8 = 5, 8
 CMP_LE, CMP_LT, CMP_EQ, CMP_GE, CMP_GT = 0, 1, 2, 3, 4
-MAX_L, MAX_K, MAX_N_KNN, LEV_MAX_BAND = 128, 63, 1 << 24, 8
+MAX_L, MAX_L_5BIT, MAX_K, MAX_N_KNN, LEV_MAX_BAND = 128, 255, 63, 1 << 24, 8
 
 # every symbol include/prograph_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
@@ -170,8 +170,8 @@ def pack(tokens, rows=None, bits=None, width=None):
     lw = l if width is None else int(width)
     if lw < l:
         raise ValueError("width smaller than the token matrix")
-    if lw > MAX_L:
-        raise ValueError(f"L={lw} exceeds the native limit of {MAX_L}")
+    if lw > MAX_L_5BIT:
+        raise ValueError(f"L={lw} exceeds the native limit of {MAX_L_5BIT}")
     ridx = None
     n = n_src
     if rows is not None:
@@ -187,6 +187,8 @@ def pack(tokens, rows=None, bits=None, width=None):
         if lo < 0 or hi > 255:
             raise ValueError("tokens outside 0..255 cannot use the byte-token Hamming path")
         bits = BITS_5 if hi <= 31 else BITS_8
+    if lw > (MAX_L_5BIT if bits == BITS_5 else MAX_L):
+        raise ValueError(f"L={lw} exceeds the native limit for {bits} bit planes")
     np_ = npad(n)
     if lw != l:
         wide = torch.zeros((n_src, lw), dtype=tokens.dtype, device=dev)   # clean_input's zero right-padding

@@ -269,9 +269,13 @@ __global__ __launch_bounds__(256) void pg_csr_row_stats_kernel(const long long *
 // =======================================================================================
 // host side of the ABI
 // =======================================================================================
-static int check_l(int l) {
+// `l` may be the packed width rounded up to whole 32-token groups (256 for 8 groups); only
+// pg_pack_planes, which sees the real tokens, enforces L <= 255 (a distance must fit uint8).
+static int check_l(int l, int bits = 8, bool exact = false) {
   if (l <= 0) return fail(PG_E_BADARG, "sequence length must be positive");
-  if (l > PG_MAX_L) return fail(PG_E_TOOLONG, "sequence length exceeds PG_MAX_L (128 bytes)");
+  const int maxg = bits == 5 ? PG_MAX_L_5BIT / 32 + 1 : PG_MAX_L / 32;
+  if ((l + 31) / 32 > maxg || (exact && l > (bits == 5 ? PG_MAX_L_5BIT : PG_MAX_L)))
+    return fail(PG_E_TOOLONG, "sequence length exceeds the native limit (128 tokens, 255 with 5 bit planes)");
   return 0;
 }
 static int check_bits(int b) {
@@ -303,10 +307,13 @@ static void eps_interval(int cmp, double eps, u32 *lo, u32 *span) {
 typedef int (*nsq_fn)(int, int, const NsqParams &, int, hipStream_t);
 typedef int (*dense_fn)(int, const DenseParams &, hipStream_t);
 typedef int (*compact_fn)(int, const CompactParams &, hipStream_t);
-static const nsq_fn kNsq[4] = {pg_launch_nsq_g1, pg_launch_nsq_g2, pg_launch_nsq_g3, pg_launch_nsq_g4};
-static const dense_fn kDense[4] = {pg_launch_dense_g1, pg_launch_dense_g2, pg_launch_dense_g3, pg_launch_dense_g4};
-static const compact_fn kCompact[4] = {pg_launch_compact_g1, pg_launch_compact_g2, pg_launch_compact_g3,
-                                       pg_launch_compact_g4};
+static const nsq_fn kNsq[8] = {pg_launch_nsq_g1, pg_launch_nsq_g2, pg_launch_nsq_g3, pg_launch_nsq_g4,
+                               pg_launch_nsq_g5, pg_launch_nsq_g6, pg_launch_nsq_g7, pg_launch_nsq_g8};
+static const dense_fn kDense[8] = {pg_launch_dense_g1, pg_launch_dense_g2, pg_launch_dense_g3, pg_launch_dense_g4,
+                                   pg_launch_dense_g5, pg_launch_dense_g6, pg_launch_dense_g7, pg_launch_dense_g8};
+static const compact_fn kCompact[8] = {pg_launch_compact_g1, pg_launch_compact_g2, pg_launch_compact_g3,
+                                       pg_launch_compact_g4, pg_launch_compact_g5, pg_launch_compact_g6,
+                                       pg_launch_compact_g7, pg_launch_compact_g8};
 
 // Static, even split of the rows over the resident waves: every row costs the same (one
 // sweep over all columns), so equal row counts are equal work.  Each wave then walks its
@@ -333,8 +340,8 @@ extern "C" {
 int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld, const int64_t *rows, int bits,
                    void *planes, int64_t npad, uint32_t *flags, void *stream) {
   if (!src || !planes || !flags || n < 0 || ld < l) return fail(PG_E_BADARG, "pg_pack_planes: bad argument");
-  if (int rc = check_l(l)) return rc;
   if (int rc = check_bits(bits)) return rc;
+  if (int rc = check_l(l, bits, true)) return rc;
   if (npad < n || npad % 256) return fail(PG_E_BADARG, "pg_pack_planes: npad must be pg_npad(n)");
   const int ng = pg_ngroups(l), nq = pg_nchunks(l, bits);
   hipStream_t s = (hipStream_t)stream;
@@ -363,8 +370,8 @@ int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad, const void
                      int l, int bits, void *out, int out_elem_bytes, int64_t ldo, void *stream) {
   if (!x_planes || !y_planes || !out || n <= 0 || m <= 0 || ldo < n)
     return fail(PG_E_BADARG, "pg_hamming_dense: bad argument");
-  if (int rc = check_l(l)) return rc;
   if (int rc = check_bits(bits)) return rc;
+  if (int rc = check_l(l, bits)) return rc;
   if (out_elem_bytes != 1 && out_elem_bytes != 4 && out_elem_bytes != 8)
     return fail(PG_E_BADARG, "pg_hamming_dense: out_elem_bytes must be 1, 4 or 8");
   if (x_npad < n || x_npad % 256 || y_npad < m) return fail(PG_E_BADARG, "pg_hamming_dense: bad npad");
@@ -379,8 +386,8 @@ int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad, const void
 static int fill_nsq(NsqParams *p, const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
                     const void *col_planes, int64_t col_npad, int64_t ncols, int l, int bits) {
   if (!row_planes || !col_planes || row0 < 0 || nrows <= 0 || ncols <= 0) return fail(PG_E_BADARG, "bad argument");
-  if (int rc = check_l(l)) return rc;
   if (int rc = check_bits(bits)) return rc;
+  if (int rc = check_l(l, bits)) return rc;
   if (col_npad < ncols || col_npad % 256 || row_npad < row0 + nrows) return fail(PG_E_BADARG, "bad npad");
   if (ncols > 0x7fffffffLL) return fail(PG_E_TOOMANY, "ncols exceeds int32 indices");
   memset(p, 0, sizeof(*p));
@@ -458,8 +465,8 @@ int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int bits,
                    const uint32_t *want_dist, int pos_mode, const uint32_t *pos_mask, const uint32_t *not_mask,
                    uint8_t *dist_out, uint64_t *hist, uint8_t *flags, void *stream) {
   if (!planes || n <= 0 || npad < n || ref < 0 || ref >= n) return fail(PG_E_BADARG, "pg_index_flags: bad argument");
-  if (int rc = check_l(l)) return rc;
   if (int rc = check_bits(bits)) return rc;
+  if (int rc = check_l(l, bits)) return rc;
   if (pos_mode < 0 || pos_mode > 2 || (pos_mode && (!pos_mask || !not_mask)))
     return fail(PG_E_BADARG, "pg_index_flags: bad position mode / masks");
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);

@@ -33,7 +33,7 @@ enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1 };
 //   group costs  1 v_xor + (B-1) v_bitop3 + 1 v_bcnt(+acc)  =  B+1 VALU ops per 32 tokens:
 //   6 ops for 5-bit alphabets (the 20 amino acids + pad), 9 for full bytes.
 // ---------------------------------------------------------------------------------------
-#define PG_MAX_G 4          // groups of 32 positions: L <= 128
+#define PG_MAX_G 8          // groups of 32 positions: L <= 255 for 5-bit tokens (G <= 4, L <= 128 for bytes)
 #define PG_BITOP_XOR_OR 0xBE
 
 // A VGPR that holds 0 in every lane but that the compiler must treat as divergent.  LLVM's
@@ -96,7 +96,7 @@ __device__ __forceinline__ u32 mismatch_lb(const uint4 &r0, const uint4 &c0) {
   if constexpr (G > 1) acc += __builtin_popcount(r0.y ^ c0.y);
   if constexpr (G > 2) acc += __builtin_popcount(r0.z ^ c0.z);
   if constexpr (G > 3) acc += __builtin_popcount(r0.w ^ c0.w);
-  return acc;
+  return acc;      // G > 4: chunk 0 covers the first 128 positions only — still a lower bound
 }
 
 // Metric policies of the all-pairs engine: record size in 16-byte chunks + the pair function.
@@ -183,7 +183,7 @@ struct CompactParams {
   int pg_launch_nsq_g##G(int mode, int bits, const NsqParams &p, int grid, hipStream_t s);   \
   int pg_launch_dense_g##G(int bits, const DenseParams &p, hipStream_t s);                    \
   int pg_launch_compact_g##G(int bits, const CompactParams &p, hipStream_t s);
-PG_DECL_G(1) PG_DECL_G(2) PG_DECL_G(3) PG_DECL_G(4)
+PG_DECL_G(1) PG_DECL_G(2) PG_DECL_G(3) PG_DECL_G(4) PG_DECL_G(5) PG_DECL_G(6) PG_DECL_G(7) PG_DECL_G(8)
 int pg_launch_nsq_bag(const NsqParams &p, int grid, hipStream_t s);   // pg_lev.hip
 int pg_launch_lev_profile(const unsigned char *tok, long long n, int l, long long ld, u32 *prof, long long npad,
                           int *lens, u32 *flags, hipStream_t s);

@@ -1,8 +1,10 @@
-// Compiled once per PG_G (1..4 groups of 32 positions) so the variants build in parallel.
+// Compiled once per PG_G (1..8 groups of 32 positions) so the variants build in parallel.
+// Byte alphabets (8 planes) are instantiated up to G = 4 (L <= 128); beyond that the record no
+// longer fits two register sets and callers take the generic path.
 #include "pg_nsq.h"
 
 #ifndef PG_G
-#error "compile with -DPG_G=<1..4>"
+#error "compile with -DPG_G=<1..8>"
 #endif
 
 #define PG_CAT_(a, b) a##b
@@ -13,12 +15,17 @@ template <int B>
 struct Cols {
   static constexpr int Q = Rec<PG_G, B>::Q;
   static constexpr int C = Q <= 3 ? 4 : (Q <= 6 ? 2 : 1);
+  static constexpr bool kBuilt = (B == 5) || (PG_G <= 4);
 };
 
 template <int B, int MODE>
 static int launch_nsq(const NsqParams &p, int grid, hipStream_t s) {
-  pg_nsq_kernel<HammingMetric<PG_G, B>, Cols<B>::C, MODE><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
-  return (int)hipGetLastError();
+  if constexpr (Cols<B>::kBuilt) {
+    pg_nsq_kernel<HammingMetric<PG_G, B>, Cols<B>::C, MODE><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+    return (int)hipGetLastError();
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
 }
 
 int PG_CAT(pg_launch_nsq_g, PG_G)(int mode, int bits, const NsqParams &p, int grid, hipStream_t s) {
@@ -28,6 +35,7 @@ int PG_CAT(pg_launch_nsq_g, PG_G)(int mode, int bits, const NsqParams &p, int gr
 
 template <int B>
 static int launch_dense(const DenseParams &p, hipStream_t s) {
+  if constexpr (!Cols<B>::kBuilt) return (int)hipErrorInvalidValue;
   const dim3 grid((unsigned)((p.n + PG_WG_THREADS - 1) / PG_WG_THREADS), (unsigned)((p.m + PG_RBD - 1) / PG_RBD));
   if (p.outBytes == 8)
     pg_dense_kernel<PG_G, B, long long><<<grid, dim3(PG_WG_THREADS), 0, s>>>(p);
@@ -44,9 +52,11 @@ int PG_CAT(pg_launch_dense_g, PG_G)(int bits, const DenseParams &p, hipStream_t 
 
 int PG_CAT(pg_launch_compact_g, PG_G)(int bits, const CompactParams &p, hipStream_t s) {
   const unsigned grid = (unsigned)((p.e.nrows + PG_WG_WAVES - 1) / PG_WG_WAVES);
-  if (bits == 5)
+  if (bits == 5) {
     pg_compact_kernel<PG_G, 5><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
-  else
-    pg_compact_kernel<PG_G, 8><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+  } else {
+    if constexpr (Cols<8>::kBuilt) pg_compact_kernel<PG_G, 8><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+    else return (int)hipErrorInvalidValue;
+  }
   return (int)hipGetLastError();
 }

@@ -38,11 +38,15 @@ def hamming(X, Y, similarity=False):
     dev = _native.device()
     Xd, Yd = X.to(dev), Y.to(dev)
     xb = yb = None
-    if X.shape[1] <= _native.MAX_L:
+    if X.shape[1] <= _native.MAX_L_5BIT:
         xb = _as_byte_tokens(Xd)
         yb = _as_byte_tokens(Yd) if xb is not None else None
+    bits = None
     if xb is not None and yb is not None:
         bits = _native.BITS_5 if max(int(xb.max()), int(yb.max())) <= 31 else _native.BITS_8
+        if bits == _native.BITS_8 and X.shape[1] > _native.MAX_L:
+            xb = yb = None                       # byte alphabets are native up to 128 tokens only
+    if xb is not None and yb is not None:
         distances = _native.hamming_dense(_native.pack(xb, bits=bits), _native.pack(yb, bits=bits), out_bytes=8)
     else:
         distances = torch.sum(Xd != Yd[:, None, :], axis=2)

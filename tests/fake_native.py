@@ -32,7 +32,7 @@ def _pack(tokens, rows=None, bits=None, width=None):
         raise TypeError("integer tokens expected")
     if width is not None:
         t = _pad_to(t, width)
-    if t.shape[1] > _native.MAX_L:
+    if t.shape[1] > _native.MAX_L_5BIT:
         raise ValueError("L exceeds the native limit")
     if rows is not None:
         t = t[np.asarray(rows)]
@@ -43,6 +43,8 @@ def _pack(tokens, rows=None, bits=None, width=None):
     bits = bits or (8 if t.size and t.max() > 31 else 5)
     if t.size and t.max() >= (1 << bits):
         raise ValueError("tokens do not fit the bit planes")
+    if t.shape[1] > (_native.MAX_L_5BIT if bits == 5 else _native.MAX_L):
+        raise ValueError("L exceeds the native limit for these bit planes")
     return FakePlanes(t, bits)
 
 

@@ -97,12 +97,12 @@ def test_row_window_equals_full(nat):
 
 def test_dense_kats(nat):
     g = load_golden("hamming_kats")
-    for i in range(4):       # r4/r5 exceed 128 tokens: not a native shape
+    for i in range(6):       # r4/r5 are 130 / 200 tokens wide: native with 5 bit planes only
         X, Y = g[f"r{i}_X"], g[f"r{i}_Y"]
         D = max(X.shape[1], Y.shape[1])
         Xp = np.zeros((X.shape[0], D), np.uint8); Xp[:, :X.shape[1]] = X
         Yp = np.zeros((Y.shape[0], D), np.uint8); Yp[:, :Y.shape[1]] = Y
-        for bits in BITS:
+        for bits in (BITS if D <= 128 else [5]):
             out = nat.hamming_dense(_planes(nat, Xp, bits), _planes(nat, Yp, bits))
             assert out.dtype == torch.int64 and np.array_equal(out.cpu().numpy(), g[f"r{i}_out"])
     X, Y = g["wide_X"], g["wide_Y"]
@@ -117,12 +117,12 @@ def test_dense_kats(nat):
 def test_dense_vs_oracle_all_q(nat):
     from oracle import prograph_oracle as O
     rng = np.random.RandomState(5)
-    for L in [1, 3, 16, 17, 31, 33, 48, 64, 65, 80, 96, 100, 112, 127, 128]:
+    for L in [1, 3, 16, 17, 31, 33, 48, 64, 65, 80, 96, 100, 112, 127, 128, 129, 160, 161, 200, 224, 254, 255]:
         X = rng.randint(0, 21, size=(300, L)).astype(np.uint8)
         Y = X[rng.randint(0, 300, size=70)].copy()
         Y[:, rng.randint(0, L)] = 0
         ref = O.hamming(X.astype(np.int64), Y.astype(np.int64)).numpy()
-        for bits in BITS:
+        for bits in (BITS if L <= 128 else [5]):
             out = nat.hamming_dense(_planes(nat, X, bits), _planes(nat, Y, bits))
             assert np.array_equal(out.cpu().numpy(), ref), (L, bits)
 
@@ -131,12 +131,12 @@ def test_engine_vs_oracle_all_q(nat):
     """eps + kNN engines against the oracle for every chunk count Q=1..8 (L up to 128)."""
     from oracle import prograph_oracle as O
     from prograph_amd import synth
-    for L in [5, 16, 24, 40, 50, 64, 70, 90, 100, 128]:
+    for L in [5, 16, 24, 40, 50, 64, 70, 90, 100, 128, 129, 150, 192, 200, 230, 255]:
         tok = synth.clustered_tokens(700, L, seed=100 + L, members=100)
         tok[13] = tok[400]
         ref_e = O.neighbours_to_csr(O.build_graph(tok.astype(np.int64), eps=3))
         ref_k = O.neighbours_to_knn(O.build_graph(tok.astype(np.int64), k=7))
-        for bits in BITS:
+        for bits in (BITS if L <= 128 else [5]):
             p = _planes(nat, tok, bits)
             ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 3))
             assert np.array_equal(ip, ref_e[0]) and np.array_equal(ix, ref_e[1]) and np.array_equal(w, ref_e[2]), (L, bits)
@@ -213,8 +213,11 @@ def test_pack_flags_and_errors(nat):
         nat.pack(torch.from_numpy(np.array([[1, 2, 300]], dtype=np.int64)))
     with pytest.raises(ValueError):
         nat.pack(torch.from_numpy(np.array([[1, -2, 3]], dtype=np.int64)))
+    assert nat.pack(torch.zeros((4, 129), dtype=torch.uint8)).g == 5            # 5 bit planes: up to 255 tokens
     with pytest.raises(ValueError):
-        nat.pack(torch.zeros((4, 129), dtype=torch.uint8))
+        nat.pack(torch.zeros((4, 256), dtype=torch.uint8))
+    with pytest.raises(ValueError):
+        nat.pack(torch.full((4, 129), 200, dtype=torch.uint8))                   # byte alphabets: up to 128
     p = nat.pack(torch.ones((10, 8), dtype=torch.uint8))
     with pytest.raises(RuntimeError):
         nat.knn_graph(p, p, 64)
@@ -405,8 +408,8 @@ def test_randomised_shapes_against_c_oracle(nat):
     rng = np.random.RandomState(20260104)
     for it in range(40):
         N = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 256, 257, 700, 1500, 2600]))
-        L = int(rng.randint(1, 129))
         amax = int(rng.choice([1, 2, 4, 20, 31, 32, 127, 255]))
+        L = int(rng.randint(1, 256 if amax <= 31 else 129))
         base = rng.randint(0, amax + 1, size=(max(1, N // 40), L))
         tok = base[rng.randint(0, len(base), size=N)].copy()
         nmut = rng.randint(0, 4, size=N)
@@ -414,7 +417,7 @@ def test_randomised_shapes_against_c_oracle(nat):
             for _ in range(nmut[r]):
                 tok[r, rng.randint(0, L)] = rng.randint(0, amax + 1)
         tok = tok.astype(np.uint8)
-        bits = 5 if (amax <= 31 and rng.rand() < 0.7) else 8
+        bits = 5 if (amax <= 31 and (L > 128 or rng.rand() < 0.7)) else 8
         p = _planes(nat, tok, bits)
         row0 = int(rng.randint(0, N)); nrows = int(rng.randint(1, N - row0 + 1))
         cmp = int(rng.randint(0, 5)); eps = float(rng.choice([1, 2, 3, 5, 2.5, L, L + 3]))

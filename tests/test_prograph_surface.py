@@ -272,7 +272,7 @@ def test_hamming_operator(backend):
     out = hamming(X, Y)
     assert out.dtype == torch.int64 and out.device == X.device and tuple(out.shape) == (2, 2)
     g = load_golden("hamming_kats")
-    for i in range(6):       # incl. unequal D (zero padding) and D > 128 (generic expression)
+    for i in range(6):       # incl. unequal D (zero padding) and D > 128 (5-bit planes up to 255 tokens)
         got = hamming(g[f"r{i}_X"].astype(np.int64), g[f"r{i}_Y"].astype(np.int64))
         assert np.array_equal(got.numpy(), g[f"r{i}_out"]), i
     assert np.array_equal(hamming(g["wide_X"], g["wide_Y"]).numpy(), g["wide_out"])
