@@ -87,7 +87,8 @@ def _load():
         lib.pg_csr_row_stats.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]
         lib.pg_lev_profile.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp]
         lib.pg_lev_candidates.argtypes = [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]
-        lib.pg_lev_knn.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]
+        lib.pg_lev_knn.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
+                                   _vp]
         for name in SYMBOLS:
             fn = getattr(lib, name)
             if fn.restype is ctypes.c_int and name not in ("pg_version",):
@@ -350,6 +351,9 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
            "pg_lev_profile")
     if int(flags.item()):
         raise ValueError("levenshtein_knn: tokens must be 1..31 with zeros only as right padding")
+    if l > 128:
+        raise ValueError("levenshtein_knn: at most 128 tokens per sequence")
+    planes = pack(tokens, bits=BITS_5, width=128)            # chunk p of a record = bit plane p (128 bits)
     counts = torch.empty(nrows, dtype=torch.int32, device=dev)
     passes = 0
     while True:
@@ -364,7 +368,8 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
         cap = ((mx + 63) // 64) * 64          # some row has more candidates than slots: redo with room
     idx = torch.empty((nrows, k), dtype=torch.int32, device=dev)
     dist = torch.empty((nrows, k), dtype=torch.uint8, device=dev)
-    _check(L.pg_lev_knn(_ptr(tokens), n, l, tokens.stride(0), _ptr(lens), row0, nrows, int(band), int(k), int(cap),
+    _check(L.pg_lev_knn(_ptr(tokens), n, l, tokens.stride(0), _ptr(planes.buf), planes.npad, _ptr(lens), row0, nrows,
+                        int(band), int(k), int(cap),
                         _ptr(slot_idx), _ptr(counts), _ptr(idx), _ptr(dist), _stream()), "pg_lev_knn")
     if return_stats:
         return idx, dist, {"candidates": int(counts.to(torch.int64).sum().item()), "cap": cap, "filter_passes": passes}

@@ -512,17 +512,18 @@ int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row
   return launched(pg_launch_nsq_bag(p, grid, (hipStream_t)stream), "pg_nsq_kernel(bag)");
 }
 
-int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const int32_t *lens, int64_t row0, int64_t nrows,
+int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const void *planes128, int64_t npad,
+               const int32_t *lens, int64_t row0, int64_t nrows,
                int band, int k, int cap, const int32_t *slot_idx, const uint32_t *counts, int32_t *idx_out,
                uint8_t *dist_out, void *stream) {
-  if (!tokens || !lens || !slot_idx || !counts || !idx_out || !dist_out || n <= 0 || nrows <= 0 || row0 < 0 ||
+  if (!tokens || !planes128 || npad < n || npad % 256 || !lens || !slot_idx || !counts || !idx_out || !dist_out || n <= 0 || nrows <= 0 || row0 < 0 ||
       row0 + nrows > n || ld < l || cap < 0)
     return fail(PG_E_BADARG, "pg_lev_knn: bad argument");
   if (int rc = check_l(l)) return rc;
   if (band < 0 || band > PG_LEV_MAX_BAND) return fail(PG_E_BADARG, "pg_lev_knn: band must be in 0..8");
   if (k < 1 || k > PG_MAX_K) return fail(PG_E_BADARG, "pg_lev_knn: k must be in 1..63");
   if (n > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_lev_knn: n exceeds 2^24");
-  return launched(pg_launch_lev_select(tokens, n, l, ld, lens, row0, nrows, band, k, (u32)cap, slot_idx, counts,
+  return launched(pg_launch_lev_select(tokens, n, l, ld, (const uint4 *)planes128, npad, lens, row0, nrows, band, k, (u32)cap, slot_idx, counts,
                                        idx_out, dist_out, (hipStream_t)stream), "pg_lev_select_kernel");
 }
 

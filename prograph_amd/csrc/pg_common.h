@@ -187,6 +187,7 @@ PG_DECL_G(1) PG_DECL_G(2) PG_DECL_G(3) PG_DECL_G(4) PG_DECL_G(5) PG_DECL_G(6) PG
 int pg_launch_nsq_bag(const NsqParams &p, int grid, hipStream_t s);   // pg_lev.hip
 int pg_launch_lev_profile(const unsigned char *tok, long long n, int l, long long ld, u32 *prof, long long npad,
                           int *lens, u32 *flags, hipStream_t s);
-int pg_launch_lev_select(const unsigned char *tok, long long n, int l, long long ld, const int *lens, long long row0,
+int pg_launch_lev_select(const unsigned char *tok, long long n, int l, long long ld, const uint4 *planes,
+                         long long npad, const int *lens, long long row0,
                          long long nrows, int band, int k, u32 cap, const int *slotIdx, const u32 *counts,
                          int *knnIdx, unsigned char *knnDist, hipStream_t s);

@@ -12,10 +12,11 @@
 //     and the length by <= 1, so  max(SAD, 2*|dlen|) <= 2*band  is a NECESSARY condition for
 //     d <= band.  10 VALU ops per pair; survivors (ascending column order, exact counts) land
 //     in per-row candidate slots exactly like the epsilon graph.
-//  3. pg_lev_select_kernel: one wave per row, one candidate per lane: exact banded DP
-//     (Wagner–Fischer on the 2*band+1 diagonals, 4 VALU ops per cell), sorted insertion of
-//     (d << 24 | column) keys into the 64-lane register list, then the ranks that no candidate
-//     within the band fills are taken by the smallest column indices at distance band+1.
+//  3. pg_lev_select_kernel: one wave per row, one candidate per lane: exact banded edit distance
+//     with the bit-parallel diagonal-band recurrence of Myers / Hyyrö (one 17-bit delta vector
+//     pair per lane, ~24 VALU ops per text character instead of 4 per DP cell x 17 cells), sorted
+//     insertion of (d << 24 | column) keys into the 64-lane register list, then the ranks that no
+//     candidate within the band fills are taken by the smallest column indices at distance band+1.
 #include "pg_nsq.h"
 
 #define PG_LEV_MAXL 128
@@ -65,9 +66,11 @@ __global__ __launch_bounds__(256) void pg_lev_profile_kernel(const unsigned char
 // stage 3: exact banded DP per candidate + kNN selection, one wave per row
 // ---------------------------------------------------------------------------------------
 struct LevParams {
-  const unsigned char *tok;
+  const unsigned char *tok;     // row-major tokens (the wave's own row is read from here)
   long long n, ld;
   int l;
+  const uint4 *planes;          // the same tokens bit-sliced with 5 planes at width 128: chunk p = plane p
+  long long npad;
   const int *lens;
   long long row0, nrows;
   int band, k;
@@ -78,10 +81,22 @@ struct LevParams {
   unsigned char *knnDist;
 };
 
+// Banded edit distance, bit-parallel (Hyyrö 2003, diagonal band).  The row sequence a is the
+// "text" (wave uniform), the lane's candidate b the "pattern".  For text position j the window
+// bit r stands for pattern row i = j - B + r (r = 0..2B); VP/VN are the vertical +1/-1 deltas of
+// the previous column already shifted to this window, and per column
+//     Eq[r] = (b[j-B+r] == a[j])
+//     D0 = (((Eq & VP) + VP) ^ VP) | Eq | VN          diagonal delta is zero
+//     HP = VN | ~(D0 | VP);   HN = D0 & VP            horizontal deltas
+//     X  = D0 >> 1;   VN = X & HP;   VP = HN | ~(X | HP) | top
+// The cell (lb, la) lies on diagonal kf = lb - la = window bit B + kf, and along a diagonal the
+// value grows by 1 - D0[bit]: distance = |kf| + la - sum_j D0_j[B + kf].  Initial vectors encode
+// D[i][0] = |i| for the sentinel-extended strings: VP = bits >= B, VN = bits < B.
+// Eq comes from b's five 128-bit planes: the window is a funnel shift (v_alignbit) of two
+// adjacent plane dwords, and "plane bit equals a's bit" is folded with v_bitop3 against a mask
+// (0 / ~0 per plane of a[j]) that the wave precomputes once per row in LDS.
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_lev_select_kernel(const LevParams p) {
-  // per wave: the row's tokens (bytes) and the 64 candidates' tokens as dwords, lane-interleaved
-  __shared__ u32 ldsA[PG_WG_WAVES][PG_LEV_MAXL / 4];
-  __shared__ u32 ldsB[PG_WG_WAVES][PG_LEV_MAXL / 4 + 8][64];
+  __shared__ uint4 amask[PG_WG_WAVES][PG_LEV_MAXL][2];   // per text position: masks of planes 0..3 | plane 4
   __shared__ u32 ldsF[PG_WG_WAVES][64];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -91,22 +106,18 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_lev_select_kernel(const LevP
   const int la = __builtin_amdgcn_readfirstlane(p.lens[row]);
   const int B = p.band;
   const u32 capd = (u32)B + 1u;
-  const int nw = (p.l + 3) >> 2;                       // dwords per token row
-  const u32 INF = 1000u;
+  const u32 wbits = 2u * (u32)B + 1u;
+  const u32 top = 1u << (wbits - 1u);
 
-  if (lane < PG_LEV_MAXL / 4) {
-    u32 v = 0;
-    if (lane < nw) {
-      const unsigned char *ra = p.tok + row * p.ld + lane * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v |= (lane * 4 + j < p.l ? (u32)ra[j] : 0u) << (8 * j);
-    }
-    ldsA[wv][lane] = v;
+  for (int j = lane; j < PG_LEV_MAXL; j += 64) {
+    const u32 t = j < p.l ? (u32)p.tok[row * p.ld + j] : 0u;
+    amask[wv][j][0] = make_uint4(0u - (t & 1u), 0u - ((t >> 1) & 1u), 0u - ((t >> 2) & 1u), 0u - ((t >> 3) & 1u));
+    amask[wv][j][1] = make_uint4(0u - ((t >> 4) & 1u), 0u, 0u, 0u);
   }
-  // zero the tail dwords a window may touch beyond the row width
-  for (int w = nw; w < PG_LEV_MAXL / 4 + 8; ++w) ldsB[wv][w][lane] = 0;
-  const unsigned char *abytes = reinterpret_cast<const unsigned char *>(&ldsA[wv][0]);
-  const unsigned char *bbytes = reinterpret_cast<const unsigned char *>(&ldsB[wv][0][0]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint4 *am = &amask[wv][0][0] + opaque_zero();
 
   u32 lst = 0xFFFFFFFFu, thr = 0xFFFFFFFFu;            // sorted keys across lanes / (k+1)-th key
   const u32 cnt = p.counts[lr];
@@ -116,70 +127,54 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_lev_select_kernel(const LevP
     const bool have = c0 + lane < ncand;
     const int col = have ? p.slotIdx[lr * (long long)p.cap + c0 + lane] : 0;
     const int lb = have ? p.lens[col] : 0;
-    __builtin_amdgcn_wave_barrier();
-    for (int w = 0; w < nw; ++w) {
-      u32 v = 0;
-      if (have) {
-        const unsigned char *rb = p.tok + (long long)col * p.ld + w * 4;
+    u32 P[5][6];                                        // plane p as dwords [zero, w0, w1, w2, w3, zero]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v |= (w * 4 + j < p.l ? (u32)rb[j] : 0u) << (8 * j);
+    for (int q = 0; q < 5; ++q) {
+      const uint4 v = p.planes[(long long)q * p.npad + col];
+      P[q][0] = 0u; P[q][1] = v.x; P[q][2] = v.y; P[q][3] = v.z; P[q][4] = v.w; P[q][5] = 0u;
+    }
+    const int kf = lb - la;
+    const bool done = !have || kf > B || kf < -B;
+    const u32 rbit = (u32)(B + (done ? 0 : kf));
+    u32 VP = ((1u << wbits) - 1u) & ~((1u << B) - 1u);
+    u32 VN = (1u << B) - 1u;
+    u32 zsum = 0;                                       // number of columns with D0[rbit] = 1
+    bool alive = true;                                  // some lane can still end within the band
+    // window start in the zero-extended 192-bit plane: bit offset j - B - 1 + 32 (>= 24)
+#pragma unroll
+    for (int seg = 0; seg < 5; ++seg) {
+      int j0 = 32 * seg - 31 + B, j1 = 32 * seg + B;
+      if (j0 < 1) j0 = 1;
+      if (j1 > la) j1 = la;
+      for (int j = j0; j <= j1 && alive; ++j) {
+        const u32 sh = (u32)(j - B - 1 + 32) & 31u;
+        const uint4 m03 = am[(j - 1) * 2];
+        const u32 m4 = am[(j - 1) * 2 + 1].x;
+        const u32 mk[5] = {m03.x, m03.y, m03.z, m03.w, m4};
+        u32 Eq = ~(__builtin_amdgcn_alignbit(P[0][seg + 1], P[0][seg], sh) ^ mk[0]);
+#pragma unroll
+        for (int q = 1; q < 5; ++q) {
+          const u32 wq = __builtin_amdgcn_alignbit(P[q][seg + 1], P[q][seg], sh);
+          Eq = __builtin_amdgcn_bitop3_b32(Eq, wq, mk[q], 0x90);       // Eq & ~(wq ^ mk)
+        }
+        const u32 t = (Eq & VP) + VP;
+        const u32 D0 = __builtin_amdgcn_bitop3_b32(t, VP, Eq, 0xBE) | VN;       // ((t ^ VP) | Eq) | VN
+        const u32 HP = __builtin_amdgcn_bitop3_b32(VN, D0, VP, 0xF1);  // VN | ~(D0 | VP)
+        const u32 HN = D0 & VP;
+        const u32 X = __builtin_amdgcn_ubfe(D0, 1u, wbits - 1u);
+        VN = X & HP;
+        VP = __builtin_amdgcn_bitop3_b32(HN, X, HP, 0xF1) | top;       // HN | ~(X | HP) | top
+        zsum += __builtin_amdgcn_ubfe(D0, rbit, 1u);
+        if ((j & 7) == 0) {
+          // the diagonal value never decreases: stop once no live lane can stay within the band
+          const u32 cur = (u32)(kf < 0 ? -kf : kf) + (u32)j - zsum;
+          alive = __builtin_amdgcn_ballot_w64(!done && cur <= (u32)B) != 0;
+        }
       }
-      ldsB[wv][w][lane] = v;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // DP over diagonals k = j - i in [-B, B].  Both strings are thought of as prefixed by B
-    // matching sentinels, so the first real row starts from prev[k] = |k| and every cell of
-    // the band is a genuine cell (columns "before" b hold a sentinel that never matches).
-    u32 prev[PG_LEV_W], p1[PG_LEV_W], bw[PG_LEV_W];
-#pragma unroll
-    for (int t = 0; t < PG_LEV_W; ++t) {
-      const int kk = t - 8;
-      const u32 a = (u32)(kk < 0 ? -kk : kk);
-      prev[t] = (kk < -B || kk > B) ? INF : a;
-      p1[t] = prev[t] + 1u;
-      // window slot t holds b[i + kk]; before row 0 that is b[kk - 1 + 1]... filled below
-      bw[t] = 0xFFu;
-    }
-    // initial window for row i = 0: b[kk] for kk >= 0, sentinel for kk < 0
-#pragma unroll
-    for (int t = 8; t < PG_LEV_W; ++t) bw[t] = bbytes[(((t - 8) >> 2) * 64 + lane) * 4 + ((t - 8) & 3)];
-
     u32 result = capd;
-    bool done = !have || (lb - la > B) || (la - lb > B);
-    if (la == 0) { result = (u32)lb < capd ? (u32)lb : capd; done = true; }
-    for (int i = 0; i < la; ++i) {
-      const u32 ai = abytes[i];
-      u32 left = INF;                                   // (cur[k-1] + 1), nothing left of k = -8
-      u32 rowmin = INF;
-#pragma unroll
-      for (int t = 0; t < PG_LEV_W; ++t) {
-        const u32 diag = prev[t] + (ai != bw[t] ? 1u : 0u);
-        const u32 up = (t + 1 < PG_LEV_W) ? p1[t + 1] : INF;
-        u32 m = diag < up ? diag : up;
-        m = m < left ? m : left;
-        const int kk = t - 8;
-        if (kk < -B || kk > B) m = INF;                 // band narrower than the 17 kept diagonals
-        prev[t] = m;
-        left = m + 1u;
-        p1[t] = left;
-        rowmin = rowmin < m ? rowmin : m;
-      }
-      // slide the window: slot t <- slot t+1, the new last slot is b[i + 1 + 8]
-#pragma unroll
-      for (int t = 0; t + 1 < PG_LEV_W; ++t) bw[t] = bw[t + 1];
-      const int jn = i + 9;
-      bw[PG_LEV_W - 1] = bbytes[((jn >> 2) * 64 + lane) * 4 + (jn & 3)];
-      // every later row is >= this row's minimum: stop once no lane can still land in the band
-      if ((i & 7) == 7 && !__builtin_amdgcn_ballot_w64(!done && rowmin <= (u32)B)) break;
-    }
-    if (!done) {
-      const int kf = lb - la + 8;                       // diagonal of the final cell D[la][lb]
-      u32 v = INF;
-#pragma unroll
-      for (int t = 0; t < PG_LEV_W; ++t) v = (t == kf) ? prev[t] : v;
+    if (!done && alive) {
+      const u32 v = (u32)(kf < 0 ? -kf : kf) + (u32)la - zsum;
       result = v < capd ? v : capd;
     }
 
@@ -237,11 +232,12 @@ int pg_launch_lev_profile(const unsigned char *tok, long long n, int l, long lon
   return (int)hipGetLastError();
 }
 
-int pg_launch_lev_select(const unsigned char *tok, long long n, int l, long long ld, const int *lens, long long row0,
+int pg_launch_lev_select(const unsigned char *tok, long long n, int l, long long ld, const uint4 *planes,
+                         long long npad, const int *lens, long long row0,
                          long long nrows, int band, int k, u32 cap, const int *slotIdx, const u32 *counts,
                          int *knnIdx, unsigned char *knnDist, hipStream_t s) {
   LevParams p;
-  p.tok = tok; p.n = n; p.ld = ld; p.l = l; p.lens = lens; p.row0 = row0; p.nrows = nrows;
+  p.tok = tok; p.n = n; p.ld = ld; p.l = l; p.planes = planes; p.npad = npad; p.lens = lens; p.row0 = row0; p.nrows = nrows;
   p.band = band; p.k = k; p.cap = cap; p.slotIdx = slotIdx; p.counts = counts; p.knnIdx = knnIdx; p.knnDist = knnDist;
   pg_lev_select_kernel<<<dim3((unsigned)((nrows + PG_WG_WAVES - 1) / PG_WG_WAVES)), dim3(PG_WG_THREADS), 0, s>>>(p);
   return (int)hipGetLastError();
