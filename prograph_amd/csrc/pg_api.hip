@@ -23,6 +23,9 @@ static int launched(int rc, const char *where) {
   return 0;
 }
 
+// stage-1 lower-bound filter of the engine: adaptive by default; PG_LB_FILTER=0 disables, =2 forces it on
+static int lb_filter_mode() { return getenv("PG_LB_FILTER") ? atoi(getenv("PG_LB_FILTER")) : 1; }
+
 static int g_cus = 0;
 static int cu_count() {
   if (g_cus > 0) return g_cus;
@@ -391,8 +394,7 @@ static int fill_nsq(NsqParams *p, const void *row_planes, int64_t row_npad, int6
   if (col_npad < ncols || col_npad % 256 || row_npad < row0 + nrows) return fail(PG_E_BADARG, "bad npad");
   if (ncols > 0x7fffffffLL) return fail(PG_E_TOOMANY, "ncols exceeds int32 indices");
   memset(p, 0, sizeof(*p));
-  // plane-0 lower-bound filter: adaptive by default; PG_LB_FILTER=0 disables, =2 forces it on
-  p->filter = getenv("PG_LB_FILTER") ? atoi(getenv("PG_LB_FILTER")) : 1;
+  p->filter = lb_filter_mode();
   p->rowPlanes = (const uint4 *)row_planes; p->rowNpad = row_npad; p->row0 = row0; p->nrows = nrows;
   p->colPlanes = (const uint4 *)col_planes; p->colNpad = col_npad; p->ncols = ncols;
   return 0;
@@ -505,7 +507,8 @@ int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row
   memset(&p, 0, sizeof(p));
   p.rowPlanes = (const uint4 *)profiles; p.rowNpad = npad; p.row0 = row0; p.nrows = nrows;
   p.colPlanes = (const uint4 *)profiles; p.colNpad = npad; p.ncols = n;
-  p.lo = 0; p.span = 2u * (u32)band; p.hi1 = p.span + 1u;             // keep pairs with max(SAD, 2*|dlen|) <= 2*band, self included
+  p.lo = 0; p.span = 2u * (u32)band; p.hi1 = p.span + 1u;
+  p.filter = lb_filter_mode();             // keep pairs with max(SAD, 2*|dlen|) <= 2*band, self included
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
   int grid = 0;
   if (int rc = plan_rows(nrows, &p, &grid)) return rc;

@@ -117,8 +117,15 @@ struct HammingMetric {
 // so   max(sad, len2) <= 2 * d_edit;   9 v_sad_u8 + 1 v_max per pair.
 struct BagMetric {
   static constexpr int Q = 3;
-  static constexpr bool kHasLB = false;
-  static __device__ __forceinline__ u32 lower_bound(const uint4 &, const uint4 &) { return 0; }
+  // stage-1 bound of the engine: the SAD over the first 16 symbols (chunk 0) already exceeds
+  // 2*band for almost every unrelated pair: 4 v_sad_u8 instead of 9 + v_max
+  static constexpr bool kHasLB = true;
+  static __device__ __forceinline__ u32 lower_bound(const uint4 &r0, const uint4 &c0) {
+    u32 s = __builtin_amdgcn_sad_u8(r0.x, c0.x, 0u);
+    s = __builtin_amdgcn_sad_u8(r0.y, c0.y, s);
+    s = __builtin_amdgcn_sad_u8(r0.z, c0.z, s);
+    return __builtin_amdgcn_sad_u8(r0.w, c0.w, s);
+  }
   static __device__ __forceinline__ u32 dist(const uint4 (&r)[Q], const uint4 (&c)[Q], u32 init) {
     u32 rw[12], cw[12];
     unpack<Q>(r, rw);
