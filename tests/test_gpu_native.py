@@ -431,3 +431,23 @@ def test_randomised_shapes_against_c_oracle(nat):
         if N <= 700:
             m = min(N, 50)
             assert np.array_equal(nat.hamming_dense(p, _planes(nat, tok[:m], bits)).cpu().numpy(), C.hamming(tok, tok[:m])), (it, N, L)
+
+
+def test_hamming_operator_cache_tracks_in_place_edits(nat):
+    """hamming() remembers the packed form of a device-resident X across calls (the reference's
+    batch loop passes the same X every time); an in-place edit of X must invalidate it."""
+    from prograph_amd.distance import hamming
+    from oracle import prograph_oracle as O
+    rng = np.random.RandomState(8)
+    Xh = rng.randint(0, 21, size=(3000, 40)).astype(np.int64)
+    X = torch.from_numpy(Xh).cuda()
+    Y = X[:8].clone()
+    for _ in range(2):
+        assert np.array_equal(hamming(X, Y).cpu().numpy(), O.hamming(Xh, Xh[:8]).numpy())
+    X[5, 3] = 0; X[5, 4] = 7                      # in place: the version counter moves
+    Xh[5, 3] = 0; Xh[5, 4] = 7
+    out = hamming(X, Y)
+    assert out.device == X.device and np.array_equal(out.cpu().numpy(), O.hamming(Xh, Y.cpu().numpy()).numpy())
+    X[9, 0] = 200                                 # now a byte alphabet: repacked with 8 planes
+    Xh[9, 0] = 200
+    assert np.array_equal(hamming(X, Y).cpu().numpy(), O.hamming(Xh, Y.cpu().numpy()).numpy())
