@@ -88,15 +88,22 @@ __device__ __forceinline__ u32 mismatch(const uint4 (&r)[Rec<G, B>::Q], const ui
   return acc;
 }
 
-// LOWER BOUND of the Hamming distance from plane 0 alone (chunk 0 of both records): positions
-// whose tokens differ in bit 0 certainly differ.  1 v_xor + 1 v_bcnt per 32 tokens.
+// LOWER BOUND of the Hamming distance from plane 0 of the first PG_LB_GROUPS groups (chunk 0 of
+// both records): positions whose tokens differ in bit 0 certainly differ.  1 v_xor + 1 v_bcnt
+// per 32 tokens looked at.  Unrelated sequences differ in bit 0 at about half of their positions
+// (~16 +- 3 per group), far above the thresholds graph construction uses, so ONE group already
+// rejects them; looking at more groups only costs instructions.
+#ifndef PG_LB_GROUPS
+#define PG_LB_GROUPS 1
+#endif
 template <int G>
 __device__ __forceinline__ u32 mismatch_lb(const uint4 &r0, const uint4 &c0) {
+  constexpr int GL = G < PG_LB_GROUPS ? G : PG_LB_GROUPS;
   u32 acc = __builtin_popcount(r0.x ^ c0.x);
-  if constexpr (G > 1) acc += __builtin_popcount(r0.y ^ c0.y);
-  if constexpr (G > 2) acc += __builtin_popcount(r0.z ^ c0.z);
-  if constexpr (G > 3) acc += __builtin_popcount(r0.w ^ c0.w);
-  return acc;      // G > 4: chunk 0 covers the first 128 positions only — still a lower bound
+  if constexpr (GL > 1) acc += __builtin_popcount(r0.y ^ c0.y);
+  if constexpr (GL > 2) acc += __builtin_popcount(r0.z ^ c0.z);
+  if constexpr (GL > 3) acc += __builtin_popcount(r0.w ^ c0.w);
+  return acc;
 }
 
 // Metric policies of the all-pairs engine: record size in 16-byte chunks + the pair function.
