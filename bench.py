@@ -34,7 +34,6 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_WAVE_INSTR = 256 * 4 * 2.4e9 / 4   # measured: one wave64 integer VALU instruction per 4 cycles per SIMD
 
 WORKLOADS = {
     "cfg2": dict(N=50_000, L=32, mode="eps", eps=2, k=None, shards=1),
@@ -142,7 +141,6 @@ def main():
         per = N // wl["shards"]                 # rows per GPU, fixed (weak scaling)
         lo, hi = rank * per, (rank + 1) * per
     else:
-        per = -(-N // G)
         lo, hi = sharded.row_block(N, G, rank)
     rows_local = hi - lo
 
@@ -160,7 +158,6 @@ def main():
         shard_dev = None
     else:
         tok_host = None
-        gper = -(-N // G)
         glo, ghi = sharded.row_block(N, G, rank)
         shard_dev = torch.from_numpy(synth.clustered_tokens(N, L, row0=glo, nrows=ghi - glo)).to(dev)
 
@@ -256,14 +253,16 @@ def main():
         out_bytes = 5 * k * rows_local if wl["mode"] in ("knn", "lev") else 8 * (rows_local + 1) + 5 * result.get("nnz", 0)
         alg_bytes = float(rows_local) * N * L + rows_local * L + out_bytes      # SURVEY.md §8-d, per launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        ops_per_pair = 6 * ((L + 31) // 32) + 0.5                               # 5 bit planes: 6 VALU ops / 32 tokens + shared min/compare
-        traffic = None
+        # HBM traffic and VALU issue share are PMC measurements of this same command, collected in
+        # separate rocprofv3 passes (tools/profile.sh) and committed under profiles/
+        traffic = valu_frac = None
         pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc)).get(name, {})
+                traffic, valu_frac = rec.get("hbm_bytes_per_launch"), rec.get("valu_issue_frac")
             except Exception:
-                traffic = None
+                traffic = valu_frac = None
         line = {
             "metric": "sequence-pairs/s", "value": value, "unit": "sequence-pairs/s", "n_gpus": G,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -280,8 +279,9 @@ def main():
                          "kernel": "pg_nsq_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
                          "note": "algorithmic bytes = L per ordered pair (SURVEY.md 8-d); the operand matrix is "
                                  "cache resident so this HBM-equivalent rate is not capped at 1; the kernel is "
-                                 "VALU-issue bound, see valu_frac",
-                         "valu_frac": (rows_local * N / 64.0 / (kern_ms * 1e-3)) * ops_per_pair / VALU_WAVE_INSTR},
+                                 "VALU-issue bound: valu_frac = SQ_INSTS_VALU / time / (256 CUs x 4 SIMDs x 2.4 GHz / 4), "
+                                 "measured with rocprofv3 (profiles/pmc_summary.json)",
+                         "valu_frac": valu_frac},
         }
         if wl["mode"] == "eps":
             line["config"]["nnz"] = result.get("nnz")

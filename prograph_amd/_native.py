@@ -204,11 +204,6 @@ def pack(tokens, rows=None, bits=None, width=None):
     return Planes(buf, n, lw, bits)
 
 
-def refine_alpha(planes, max_token):
-    """Kept for callers that pass the alphabet size; the plane count is already fixed at pack time."""
-    return planes
-
-
 _TORCH_OUT = {1: torch.uint8, 4: torch.int32, 8: torch.int64}
 
 

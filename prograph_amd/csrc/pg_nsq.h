@@ -28,7 +28,7 @@ template <class M, int C, int MODE>
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
   constexpr int LROWS = MODE == PG_MODE_KNN ? PG_RB : 1;
-  __shared__ uint4 rowbuf[PG_WG_WAVES][PG_RB + 3][Q];      // +3: the row prefetch runs up to three past
+  __shared__ uint4 rowbuf[PG_WG_WAVES][PG_RB + 4][Q];      // +4: the row prefetch runs up to four past
   __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
   __shared__ uint4 bndbuf[PG_WG_WAVES][PG_RB / 4 + 2];     // kNN: per row the current (k+1)-th distance
   const int lane = threadIdx.x & 63;
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 
     // ---- stage this pass's rows into the wave's LDS region (wave private: LDS operations
     // of one wave are processed in order, the fences only pin the compiler) ----
-    for (int e = lane; e < (PG_RB + 3) * Q; e += 64) {
-      const int rr = e % (PG_RB + 3), q = e / (PG_RB + 3);
+    for (int e = lane; e < (PG_RB + 4) * Q; e += 64) {
+      const int rr = e % (PG_RB + 4), q = e / (PG_RB + 4);
       uint4 v = make_uint4(0, 0, 0, 0);
       if (rr < nr) v = p.rowPlanes[(long long)q * p.rowNpad + p.row0 + pr0 + rr];
       rowbuf[wv][rr][q] = v;

@@ -26,17 +26,16 @@ and returns ranks 1..k.  Weights are bit-identical to the reference either way.
 """
 import copy
 import operator
-from functools import reduce
 
 import numpy as np
 import pandas as pd
 import torch
 
 from . import _native
-from .distance import hamming, minkowski
+from .distance import hamming
 from .graph import CSRGraph, KNNGraph
 from .protein import Protein
-from .utils import Dataset, save, flatten
+from .utils import Dataset, flatten
 
 _CMP_CODE = {operator.le: _native.CMP_LE, operator.lt: _native.CMP_LT, operator.eq: _native.CMP_EQ,
              operator.ge: _native.CMP_GE, operator.gt: _native.CMP_GT}

@@ -52,7 +52,7 @@ def allgather_tokens(local_tokens, n_total, group=None):
 
 
 def build_graph_sharded(local_tokens, n_total, eps=None, k=None, comp_code=_native.CMP_LE, cap=256,
-                        max_token=None, group=None):
+                        bits=None, group=None):
     """
     This rank's slice of the epsilon / kNN graph of the full matrix.
       local_tokens  (rows_r, L) uint8 tensor on this rank's GPU: rows row_block(n_total, world, rank)
@@ -64,9 +64,7 @@ def build_graph_sharded(local_tokens, n_total, eps=None, k=None, comp_code=_nati
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = row_block(n_total, world, rank)
     full = allgather_tokens(local_tokens, n_total, group=group)
-    planes = _native.pack(full)
-    if max_token is not None:
-        _native.refine_alpha(planes, max_token)
+    planes = _native.pack(full, bits=bits)       # bits=None: 5 planes when every token is <= 31
     if hi <= lo:
         return None
     if eps:
