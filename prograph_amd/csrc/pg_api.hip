@@ -330,10 +330,15 @@ static int plan_rows(int64_t nrows, NsqParams *p, int *grid) {
   long long rpw = (nrows + maxWaves - 1) / maxWaves;
   const long long minRows = getenv("PG_WAVES_PER_CU") ? 1 : 6;
   if (rpw < minRows) rpw = minRows;
+  // the filtered sweep takes rows four at a time: whole groups waste no stage-1 work
+  if (rpw >= 4) rpw = (rpw + 3) / 4 * 4;
   const long long waves = (nrows + rpw - 1) / rpw;
   const long long passes = (rpw + PG_RB - 1) / PG_RB;
   p->rowsPerWave = (int)rpw;
-  p->rowsPerPass = (int)((rpw + passes - 1) / passes);
+  long long rpp = (rpw + passes - 1) / passes;
+  if (rpp >= 4) rpp = (rpp + 3) / 4 * 4;
+  if (rpp > PG_RB) rpp = PG_RB;
+  p->rowsPerPass = (int)rpp;
   *grid = (int)((waves + PG_WG_WAVES - 1) / PG_WG_WAVES);
   return 0;
 }

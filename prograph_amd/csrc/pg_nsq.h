@@ -4,7 +4,7 @@
 // :756-762 of the reference): distance(X, batch) -> mask/where or sort -> gather.
 //
 // Mapping (CDNA4, wave64):
-//   * one LANE owns C COLUMN sequences: their bit-sliced records (pg_common.h) sit in VGPRs,
+//   * one LANE owns C (= 2) COLUMN sequences: their bit-sliced records (pg_common.h) sit in VGPRs,
 //     loaded from the chunk-major layout as fully coalesced global_load_dwordx4 (1 KiB per wave
 //     instruction); the next column tile is prefetched into a second register set while the
 //     current one is being compared;

@@ -7,14 +7,20 @@
 #error "compile with -DPG_G=<1..8>"
 #endif
 
+#ifndef PG_CSEL
+// measured (N = 200k, L = 64): C = 2 keeps the kernel at 113 VGPRs = 4 waves per SIMD and beats
+// C = 4 (167 VGPRs, 3 waves) by 10-15 %; the stage-1 cost per pair is the same for both
+#define PG_CSEL(Q) ((Q) <= 6 ? 2 : 1)
+#endif
 #define PG_CAT_(a, b) a##b
 #define PG_CAT(a, b) PG_CAT_(a, b)
 
 // columns per lane: two register sets of C*Q chunks must stay well under the VGPR budget
+// (override for experiments: make EXTRA='"-DPG_CSEL(Q)=4"')
 template <int B>
 struct Cols {
   static constexpr int Q = Rec<PG_G, B>::Q;
-  static constexpr int C = Q <= 3 ? 4 : (Q <= 6 ? 2 : 1);
+  static constexpr int C = PG_CSEL(Q);
   static constexpr bool kBuilt = (B == 5) || (PG_G <= 4);
 };
 
