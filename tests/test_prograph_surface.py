@@ -321,3 +321,48 @@ def test_constructor_on_synthetic_sets(backend, name, tmp_path, capsys):
     r = int(g["ref_row"])
     want = int(np.bincount(d).argmax())
     assert np.array_equal(pg.indexing(reference_seq=r, distances=want), np.where(d == want)[0])
+
+
+# ---------------------------------------------------------------- tests/tests.py:139-167: kNN / eps with minkowski on an
+# embedded representation — the generic distance-operator protocol (reference semantics on torch ops).  The reference's
+# fixture (data/knntest_pgraph.pkl) is a pickle and is not loaded; six 2-D points with the same neighbour structure
+# and the same expected answers are used instead.
+EMBEDDED = np.array([[0, 0], [0.5, 0], [4, 0], [3, 0], [4.2, 1.5], [4.95, 1.75]], dtype=np.float32)
+
+
+@pytest.fixture
+def knn_test(backend, tmp_path, capsys):
+    from prograph_amd import Prograph
+    f = tmp_path / "knntest.csv"
+    pd.DataFrame({"Sequence": list("ACDEFG"), "Fitness": [1.70406036, 0.32788095, 0.79588575, 0.5333638, -0.18089174, 0.61660484]}).to_csv(f)
+    pg = Prograph(file=str(f))
+    capsys.readouterr()
+    pg.graph["Embedded"] = list(EMBEDDED)
+    return pg
+
+
+def test_knn_graph_generation_minkowski(knn_test):
+    from prograph_amd.distance import minkowski
+    L = [x[0] for x in knn_test.build_graph(representation="Embedded", k=1, distance=minkowski)]
+    assert np.all(np.array(L).reshape(-1,) == np.array([1, 0, 3, 2, 5, 4]))
+    L = [x[0] for x in knn_test.build_graph(representation="Embedded", k=2, distance=minkowski)]
+    assert np.all(L == np.array([[1, 3], [0, 3], [3, 4], [2, 4], [5, 2], [4, 2]]))
+    with pytest.raises(ValueError):
+        knn_test.build_graph(representation="Embedded", k=0, distance=minkowski)
+    with pytest.raises(TypeError):
+        knn_test.build_graph(representation="Embedded", k=0.5, distance=minkowski)
+    knn_test.graph["Weighted"] = knn_test.build_graph(eps=2, representation="Embedded", distance=minkowski)
+    np.testing.assert_almost_equal(knn_test.degree(graph="Weighted", boolean_weights=True), np.array([1, 1, 3, 2, 3, 2]))
+    knn_test.graph["Weighted"] = knn_test.build_graph(k=1, representation="Embedded", distance=minkowski)
+    # fp16 staging like the reference (prograph.py:726): sqrt(0.625) rounds to 0.79052734
+    np.testing.assert_almost_equal(knn_test.degree(graph="Weighted"), np.array([0.5, 0.5, 1., 1., 0.79052734, 0.79052734]), decimal=3)
+
+
+def test_minkowski_operator(backend):
+    from prograph_amd.distance import minkowski
+    X = torch.Tensor([[1, 2, 3], [4, 5, 6]]); Y = torch.Tensor([[1, 2, 3], [7, 8, 9]])       # tests/tests.py:192-208
+    assert torch.allclose(minkowski(X, Y), torch.Tensor([[0.0, 5.19615242], [10.3923048454, 5.19615242]]))
+    assert torch.allclose(minkowski(X, torch.Tensor([1, 2, 3])), torch.Tensor([[0.0, 5.19615242]]))
+    assert torch.allclose(minkowski(torch.Tensor([4, 5, 6]), torch.Tensor([1, 2, 3])), torch.Tensor([[5.19615242]]))
+    with pytest.raises(ValueError):
+        minkowski(torch.Tensor([4, 5, 6]), torch.Tensor())
