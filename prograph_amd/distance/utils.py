@@ -8,9 +8,8 @@ dimension is right-padded with zeros.
 import torch
 import torch.nn.functional as F
 
-_EMPTY_MSG = ("You cannot pass an empty tensor. Empty tensors will be padded with zeros and thus is calculates "
-              "the distance from every sequence to the origin. If this is desired behaviour, manually pass a "
-              "tensor of zeros the same size as the sequence tensor of interest.")
+_EMPTY_MSG = ("An operand with zero rows was given.  Padding it would silently measure the distance of every "
+              "sequence to the all-zero sequence; pass an explicit zero tensor of the right shape if that is intended.")
 
 
 def clean_input(X, Y, verbose=False):

@@ -1,27 +1,22 @@
 """
-Persist a graph (prograph/utils/save.py:5-39 of the reference): pickle the DataFrame without
-the cheap-to-recompute `Tokenized` column to `<directory><name>.pkl`.  Like the reference it
-reports problems on stdout and returns True; a reloaded pickle that already carries a
-`Neighbours` column skips graph construction (prograph/prograph.py:140-141).
+Persist a graph to `<directory><name>.pkl` (the reference's prograph/utils/save.py:5-39): the
+DataFrame is pickled without the cheap-to-recompute `Tokenized` column.  A reloaded pickle that
+already carries a `Neighbours` column skips graph construction (prograph/prograph.py:140-141).
+Like the reference, problems are reported on stdout and the function still returns True.
 """
+import os
 
 
 def save(pgraph, name=None, ext=".pkl", directory=None, ignored_cols=["Tokenized"]):
-    file = "pgraph"
+    source = getattr(pgraph, "file", None)
+    stem = os.path.splitext(os.path.basename(source))[0] if source else "pgraph"
     if directory is None:
-        if hasattr(pgraph, "file"):
-            directory, file = pgraph.file.rsplit("/", 1)
-            directory += "/"
-        else:
-            directory = "./"
-    elif hasattr(pgraph, "file"):
-        file = pgraph.file.rsplit("/", 1)[-1]
-    if not name:
-        name = file.rsplit(".", 1)[0] + "_pgraph"
-    print(f"Saving Graph to {name + ext}")
+        directory = (os.path.dirname(source) + "/") if source and os.path.dirname(source) else "./"
+    target = directory + (name or stem + "_pgraph") + ext
+    print(f"Saving Graph to {os.path.basename(target)}")
     try:
-        keep = [c for c in pgraph.graph if c not in ignored_cols]
-        pgraph.graph[keep].to_pickle(directory + name + ext)
-    except Exception as e:
-        print("Error occurred during saving:", e)
+        columns = [c for c in pgraph.graph.columns if c not in ignored_cols]
+        pgraph.graph[columns].to_pickle(target)
+    except Exception as err:
+        print("Error occurred during saving:", err)
     return True
