@@ -120,14 +120,20 @@ def main():
     from prograph_amd import _native, synth, sharded
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PG_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get("PG_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = G > 1 or os.environ.get("PG_FORCE_DIST") == "1"      # PG_FORCE_DIST: rehearse the RCCL path with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     _native.lib()
 
     name = a.workload if a.workload != "auto" else ("cfg3" if G == 1 else "cfg3w")
@@ -228,7 +234,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

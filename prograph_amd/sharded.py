@@ -47,7 +47,13 @@ def allgather_tokens(local_tokens, n_total, group=None):
         padded[: local_tokens.shape[0]] = local_tokens
         local_tokens = padded
     full = torch.empty((per * world, L), dtype=local_tokens.dtype, device=local_tokens.device)
-    dist.all_gather_into_tensor(full, local_tokens.contiguous(), group=group)
+    if dist.get_backend(group) == "gloo" and local_tokens.is_cuda:
+        # rehearsal mode (several ranks sharing one GPU, CPU collectives): stage through the host
+        host = torch.empty((per * world, L), dtype=local_tokens.dtype)
+        dist.all_gather_into_tensor(host, local_tokens.cpu().contiguous(), group=group)
+        full.copy_(host)
+    else:
+        dist.all_gather_into_tensor(full, local_tokens.contiguous(), group=group)
     return full[:n_total]
 
 
