@@ -128,7 +128,7 @@ def test_dense_vs_oracle_all_q(nat):
 
 
 def test_engine_vs_oracle_all_q(nat):
-    """eps + kNN engines against the oracle for every chunk count Q=1..8 (L up to 128)."""
+    """eps + kNN engines against the oracle for every group count G=1..8 (L up to 255)."""
     from oracle import prograph_oracle as O
     from prograph_amd import synth
     for L in [5, 16, 24, 40, 50, 64, 70, 90, 100, 128, 129, 150, 192, 200, 230, 255]:

@@ -2,9 +2,9 @@ import sys, time, os
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from prograph_amd import _native as nat, synth
-def run(N, L, alpha, mode, iters=5):
+def run(N, L, bits, mode, iters=5):
     tok = synth.clustered_tokens(N, L)
-    p = nat.pack(torch.from_numpy(tok), bits=alpha)
+    p = nat.pack(torch.from_numpy(tok), bits=bits)
     cap = 256
     dev = p.buf.device
     si = torch.empty(N*cap, dtype=torch.int32, device=dev); sw = torch.empty(N*cap, dtype=torch.uint8, device=dev); cnt = torch.empty(N, dtype=torch.int32, device=dev)
@@ -16,9 +16,9 @@ def run(N, L, alpha, mode, iters=5):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     t = np.median(ts) / 1e3
-    print(f"N={N} L={L} alpha={alpha} {mode} wpc={os.environ.get('PG_WAVES_PER_CU','8')}: {t*1e3:.2f} ms  {N*N/t:.3e} pairs/s  alg {N*N*L/t/1e12:.2f} TB/s", flush=True)
+    print(f"N={N} L={L} bits={bits} {mode} wpc={os.environ.get("PG_WAVES_PER_CU","32")}: {t*1e3:.2f} ms  {N*N/t:.3e} pairs/s  alg {N*N*L/t/1e12:.2f} TB/s", flush=True)
 for wpc in sys.argv[1:] or ["8"]:
     os.environ["PG_WAVES_PER_CU"] = wpc
-    for alpha in (5, 8):
-        run(50000, 32, alpha, "eps"); run(50000, 32, alpha, "knn")
-        run(200000, 64, alpha, "eps"); run(200000, 64, alpha, "knn")
+    for bits in (5, 8):
+        run(50000, 32, bits, "eps"); run(50000, 32, bits, "knn")
+        run(200000, 64, bits, "eps"); run(200000, 64, bits, "knn")
