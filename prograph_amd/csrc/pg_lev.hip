@@ -23,7 +23,7 @@
 #define PG_LEV_W 17          // diagonals kept: band <= 8
 
 int pg_launch_nsq_bag(const NsqParams &p, int grid, hipStream_t s) {
-  pg_nsq_kernel<BagMetric, 4, PG_MODE_EPS><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+  pg_nsq_kernel<BagMetric, 2, PG_MODE_EPS><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
   return (int)hipGetLastError();
 }
 
