@@ -378,6 +378,15 @@ class Prograph:
         if k is not None and not isinstance(k, int):
             raise TypeError("K must be provided as an integer.")
 
+        if idxs is not None:
+            # the reference indexes a tensor with `idxs` (prograph.py:726): integer lists, boolean
+            # masks and slices all select rows; normalise to integer positions
+            if isinstance(idxs, slice):
+                idxs = np.arange(len(self))[idxs]
+            else:
+                idxs = np.asarray(idxs)
+                if idxs.dtype == bool:
+                    idxs = np.nonzero(idxs)[0]
         native = distance is hamming and (comp in _CMP_CODE) and (k is None or k <= _native.MAX_K)
         planes = None
         if native:

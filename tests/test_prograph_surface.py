@@ -245,6 +245,11 @@ def test_build_graph_matches_reference(pgraph):
     _check_tuples(pgraph.build_graph(k=3, idxs=g["sub_idxs"]), g, "knn3_sub", knn=True)
     csr = pgraph.build_graph(eps=2, output="csr")
     assert csr.nnz == int(g["eps2_indptr"][-1]) and csr.nrows == 1000
+    # idxs as a boolean mask / a slice select the same rows as the integer list
+    mask = np.zeros(1000, dtype=bool); mask[g["sub_idxs"]] = True
+    _check_tuples(pgraph.build_graph(eps=1, idxs=mask), g, "eps1_sub")
+    _check_tuples(pgraph.build_graph(eps=1, idxs=slice(100, 400)), g, "eps1_sub")
+    _check_tuples(pgraph.build_graph(k=3, idxs=list(g["sub_idxs"])), g, "knn3_sub", knn=True)
 
 
 def test_build_graph_argument_errors(pgraph):
