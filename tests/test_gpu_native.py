@@ -451,3 +451,33 @@ def test_hamming_operator_cache_tracks_in_place_edits(nat):
     X[9, 0] = 200                                 # now a byte alphabet: repacked with 8 planes
     Xh[9, 0] = 200
     assert np.array_equal(hamming(X, Y).cpu().numpy(), O.hamming(Xh, Y.cpu().numpy()).numpy())
+
+
+def test_cfg4_slice_properties(nat):
+    """BASELINE.json configs[3] on one GPU: rank 3's row block (125 000 rows) of the N = 1 000 000,
+    L = 64 problem against all columns, kNN k = 16 and eps <= 2.  Checked through sampled rows against
+    the oracle's 1 x N computation and through ordering / range properties of every row."""
+    from oracle import prograph_oracle as O
+    from prograph_amd import synth, sharded
+    N, L, k = 1_000_000, 64, 16
+    tok = synth.clustered_tokens(N, L)
+    p = nat.pack(torch.from_numpy(tok), bits=5)
+    lo, hi = sharded.row_block(N, 8, 3)
+    assert (lo, hi) == (375_000, 500_000)
+    kidx, kd = nat.knn_graph(p, p, k, row0=lo, nrows=hi - lo)
+    indptr, idx, w = nat.eps_graph(p, p, nat.CMP_LE, 2, row0=lo, nrows=hi - lo, cap=64)
+    torch.cuda.synchronize()
+    kidx, kd = kidx.cpu().numpy().astype(np.int64), kd.cpu().numpy().astype(np.int64)
+    indptr, idx, w = indptr.cpu().numpy(), idx.cpu().numpy().astype(np.int64), w.cpu().numpy()
+    kk = kd * (1 << 24) + kidx
+    assert np.all(kk[:, 1:] > kk[:, :-1]) and kidx.min() >= 0 and kidx.max() < N
+    rows = np.repeat(np.arange(hi - lo), np.diff(indptr))
+    same = rows[1:] == rows[:-1]
+    assert np.all(idx[1:][same] > idx[:-1][same]) and w.min() >= 1 and w.max() <= 2
+    t64 = tok.astype(np.int64)
+    for r in np.random.RandomState(4).choice(hi - lo, size=8, replace=False):
+        d = O.hamming(t64, t64[lo + r].reshape(1, -1)).numpy()[0]
+        order = np.argsort(d, kind="stable")[1:k + 1]
+        assert np.array_equal(kidx[r], order) and np.array_equal(kd[r], d[order])
+        cols = np.where((d <= 2) & (d > 0))[0]
+        assert np.array_equal(idx[indptr[r]:indptr[r + 1]], cols) and np.array_equal(w[indptr[r]:indptr[r + 1]], d[cols])
