@@ -151,6 +151,19 @@ int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64
                    void *stream);
 
 /*
+ * pg_knn_hamming_round — kNN beyond 63 neighbours, 63/64 ranks per all-pairs round.
+ * Round 1 (first_round = 1): like pg_knn_hamming (rank 0 dropped, ranks 1..k, k <= 63) and in
+ * addition last_keys[row] = packed key (distance << 24 | column) of the last rank written.
+ * Later rounds (first_round = 0): only pairs whose key is greater than floor_keys[row] (= the
+ * previous round's last_keys) are candidates; the k <= 64 smallest of them are written, i.e. the
+ * next k ranks of the same canonical order.  idx_out / dist_out hold nrows*k entries per round.
+ */
+int pg_knn_hamming_round(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
+                         const void *col_planes, int64_t col_npad, int64_t ncols, int l, int bits,
+                         int k, int first_round, const uint32_t *floor_keys, uint32_t *last_keys,
+                         int32_t *idx_out, uint8_t *dist_out, void *stream);
+
+/*
  * pg_index_flags — the fused 1xN pass of `Prograph.indexing` (prograph/prograph.py:
  * 298-325): distance of every sequence to reference row `ref`, a 256-bin histogram of
  * those distances (for the `d in np.unique(d_data)` assertion, :305), and

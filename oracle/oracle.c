@@ -61,7 +61,7 @@ void orc_knn(const uint8_t *T, int64_t n, int l, int64_t row0, int64_t nrows, in
 #pragma omp parallel for schedule(dynamic, 16)
   for (int64_t r = 0; r < nrows; ++r) {
     const uint8_t *a = T + (row0 + r) * l;
-    int64_t best[65];
+    int64_t best[1026];                      /* k <= 1024 */
     int nb = 0;
     for (int64_t c = 0; c < n; ++c) {
       int64_t key = ((int64_t)ham(a, T + c * l, l) << 32) | c;

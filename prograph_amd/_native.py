@@ -20,13 +20,13 @@ ABI_VERSION = 1
 
 BITS_5, BITS_8 = 5, 8
 CMP_LE, CMP_LT, CMP_EQ, CMP_GE, CMP_GT = 0, 1, 2, 3, 4
-MAX_L, MAX_L_5BIT, MAX_K, MAX_N_KNN, LEV_MAX_BAND = 128, 255, 63, 1 << 24, 8
+MAX_L, MAX_L_5BIT, MAX_K, MAX_K_ROUNDS, MAX_N_KNN, LEV_MAX_BAND = 128, 255, 63, 1023, 1 << 24, 8
 
 # every symbol include/prograph_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
     "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_pack_planes",
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
-    "pg_eps_compact", "pg_knn_hamming", "pg_index_flags", "pg_compact_flags",
+    "pg_eps_compact", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
     "pg_lev_profile", "pg_lev_candidates", "pg_lev_knn", "pg_csr_row_stats",
 ]
 
@@ -82,6 +82,8 @@ def _load():
         lib.pg_eps_compact.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_knn_hamming.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
+        lib.pg_knn_hamming_round.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp,
+                                             _vp, _vp]
         lib.pg_index_flags.argtypes = [_vp, _i64, _i64, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_compact_flags.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
         lib.pg_csr_row_stats.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]
@@ -258,8 +260,37 @@ def eps_slots_only(rp, cp, cmp, eps, row0, nrows, cap, slot_idx, slot_w, counts)
     _check(lib().pg_eps_slots(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _stream()), "pg_eps_slots")
 
 
+def knn_graph_rounds(rp, cp, k, row0=0, nrows=None):
+    """k > 63: the canonical order is produced 63 + 64 + 64 ... ranks per all-pairs round, every
+    round continuing after the previous round's last (distance, column) key."""
+    L = lib()
+    nrows = rp.n - row0 if nrows is None else int(nrows)
+    dev = rp.buf.device
+    bits = _bits2(rp, cp)
+    idx = torch.empty((nrows, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((nrows, k), dtype=torch.uint8, device=dev)
+    keys_a = torch.empty(nrows, dtype=torch.int32, device=dev)
+    keys_b = torch.empty(nrows, dtype=torch.int32, device=dev)
+    done, first = 0, True
+    while done < k:
+        kk = min(63 if first else 64, k - done)
+        ri = torch.empty((nrows, kk), dtype=torch.int32, device=dev)
+        rd = torch.empty((nrows, kk), dtype=torch.uint8, device=dev)
+        _check(L.pg_knn_hamming_round(_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, bits,
+                                      kk, 1 if first else 0, _ptr(keys_a), _ptr(keys_b), _ptr(ri), _ptr(rd), _stream()),
+               "pg_knn_hamming_round")
+        idx[:, done:done + kk] = ri
+        dist[:, done:done + kk] = rd
+        keys_a, keys_b = keys_b, keys_a
+        done += kk
+        first = False
+    return idx, dist
+
+
 def knn_graph(rp, cp, k, row0=0, nrows=None, out=None):
     """(nrows, k) int32 indices and uint8 distances, ranks 1..k of the canonical order."""
+    if k > MAX_K and out is None:
+        return knn_graph_rounds(rp, cp, k, row0=row0, nrows=nrows)
     nrows = rp.n - row0 if nrows is None else int(nrows)
     dev = rp.buf.device
     if out is None:

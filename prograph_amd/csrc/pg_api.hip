@@ -454,18 +454,36 @@ int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64
   return launched(kCompact[pg_ngroups(l) - 1](bits, c, (hipStream_t)stream), "pg_compact_kernel");
 }
 
-int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
-                   int64_t col_npad, int64_t ncols, int l, int bits, int k, int32_t *idx_out, uint8_t *dist_out,
-                   void *stream) {
+static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
+                      int64_t col_npad, int64_t ncols, int l, int bits, int k, int first, const uint32_t *floor_keys,
+                      uint32_t *last_keys, int32_t *idx_out, uint8_t *dist_out, void *stream) {
   NsqParams p;
   if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits)) return rc;
   if (!idx_out || !dist_out) return fail(PG_E_BADARG, "pg_knn_hamming: bad argument");
-  if (k < 1 || k > PG_MAX_K) return fail(PG_E_BADARG, "pg_knn_hamming: k must be in 1..63");
+  if (k < 1 || first < 0 || first > 1 || first + k > 64) return fail(PG_E_BADARG, "pg_knn_hamming: k out of range");
   if (ncols > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_knn_hamming: ncols exceeds 2^24");
-  p.k = k; p.knnIdx = idx_out; p.knnDist = dist_out;
+  p.k = k; p.knnFirst = first; p.floorKeys = floor_keys; p.lastKeys = last_keys;
+  p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;
   if (int rc = plan_rows(nrows, &p, &grid)) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");
+}
+
+int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
+                   int64_t col_npad, int64_t ncols, int l, int bits, int k, int32_t *idx_out, uint8_t *dist_out,
+                   void *stream) {
+  if (k < 1 || k > PG_MAX_K) return fail(PG_E_BADARG, "pg_knn_hamming: k must be in 1..63");
+  return knn_launch(row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits, k, 1, nullptr, nullptr,
+                    idx_out, dist_out, stream);
+}
+
+int pg_knn_hamming_round(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
+                         int64_t col_npad, int64_t ncols, int l, int bits, int k, int first_round,
+                         const uint32_t *floor_keys, uint32_t *last_keys, int32_t *idx_out, uint8_t *dist_out,
+                         void *stream) {
+  if (!last_keys || (!first_round && !floor_keys)) return fail(PG_E_BADARG, "pg_knn_hamming_round: key arrays required");
+  return knn_launch(row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits, k, first_round ? 1 : 0,
+                    first_round ? nullptr : floor_keys, last_keys, idx_out, dist_out, stream);
 }
 
 int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int bits, int64_t ref,

@@ -169,8 +169,11 @@ struct NsqParams {
   int *slotIdx;
   unsigned char *slotW;
   u32 *counts;
-  // knn
-  int k;
+  // knn: lanes [knnFirst, knnFirst + k) of the sorted 64-key list are written; keys <= floorKeys[row]
+  // are ignored (continuation rounds for k > 63); lastKeys[row] receives the last written key
+  int k, knnFirst;
+  const u32 *floorKeys;
+  u32 *lastKeys;
   int *knnIdx;
   unsigned char *knnDist;
 };

@@ -72,6 +72,12 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     //   eps: cntv = matches so far;   knn: thrv = current (k+1)-th smallest key (0xFFFFFFFF = open)
     // The kNN lists themselves sit in LDS and are only visited in the slow path.
     u32 cntv = 0u, thrv = 0xFFFFFFFFu;
+    // kNN continuation rounds (k > 63): per-row floor key, only larger keys are candidates
+    u32 floorv = 0u;
+    if constexpr (MODE == PG_MODE_KNN) {
+      if (p.floorKeys && lane < nr) floorv = p.floorKeys[pr0 + lane];
+    }
+    const int thrLane = p.knnFirst + p.k - 1;            // last list lane that is still needed
 
     // Two register sets hold the current and the next column tile; the tile loop is unrolled by
     // two so the sets swap roles instead of being copied, and the prefetch is unconditional (the
@@ -106,9 +112,11 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
         }
       } else {
         u32 thr = __builtin_amdgcn_readlane(thrv, rr);
-        u64 m = __builtin_amdgcn_ballot_w64((d < (thr >> 24)) && (col < ncols));
+        const u32 key = (d << 24) | col;
+        bool cand = (d < (thr >> 24)) && (col < ncols);
+        if (p.floorKeys) cand = cand && key > __builtin_amdgcn_readlane(floorv, rr);   // continuation round
+        u64 m = __builtin_amdgcn_ballot_w64(cand);
         if (m) {
-          const u32 key = (d << 24) | col;
           u32 lst = lstbuf[wv][rr][lane];
           do {
             const int j = __builtin_ctzll(m);
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
             if (x < thr) {
               const u32 prev = wave_shr1(lst, 0u);
               lst = (lst <= x) ? lst : (prev > x ? prev : x);
-              thr = __builtin_amdgcn_readlane(lst, p.k);
+              thr = __builtin_amdgcn_readlane(lst, thrLane);
             }
           } while (m);
           lstbuf[wv][rr][lane] = lst;
@@ -250,12 +258,13 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
       if (lane < nr) p.counts[pr0 + lane] = cntv;
     } else {
       for (int rr = 0; rr < nr; ++rr) {
-        if (lane >= 1 && lane <= p.k) {
-          const u32 key = lstbuf[wv][rr][lane];
-          const long long o = (pr0 + rr) * (long long)p.k + (lane - 1);
+        const u32 key = lstbuf[wv][rr][lane];
+        if (lane >= p.knnFirst && lane < p.knnFirst + p.k) {
+          const long long o = (pr0 + rr) * (long long)p.k + (lane - p.knnFirst);
           p.knnIdx[o] = (key == 0xFFFFFFFFu) ? -1 : (int)(key & 0x00FFFFFFu);
           p.knnDist[o] = (unsigned char)(key >> 24);
         }
+        if (p.lastKeys && lane == thrLane) p.lastKeys[pr0 + rr] = key;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

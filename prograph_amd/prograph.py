@@ -387,7 +387,7 @@ class Prograph:
                 idxs = np.asarray(idxs)
                 if idxs.dtype == bool:
                     idxs = np.nonzero(idxs)[0]
-        native = distance is hamming and (comp in _CMP_CODE) and (k is None or k <= _native.MAX_K)
+        native = distance is hamming and (comp in _CMP_CODE) and (k is None or k <= _native.MAX_K_ROUNDS)
         planes = None
         if native:
             try:

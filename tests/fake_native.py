@@ -77,7 +77,7 @@ def _eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
 
 
 def _knn_graph(rp, cp, k, row0=0, nrows=None, out=None):
-    if not 1 <= k <= _native.MAX_K:
+    if not 1 <= k <= _native.MAX_K_ROUNDS:
         raise RuntimeError("k out of range")
     rows, cols, nrows = _window(rp, cp, row0, nrows)
     d = O.hamming(cols, rows)

@@ -220,9 +220,8 @@ def test_pack_flags_and_errors(nat):
         nat.pack(torch.full((4, 129), 200, dtype=torch.uint8))                   # byte alphabets: up to 128
     p = nat.pack(torch.ones((10, 8), dtype=torch.uint8))
     with pytest.raises(RuntimeError):
-        nat.knn_graph(p, p, 64)
-    with pytest.raises(RuntimeError):
         nat.knn_graph(p, p, 0)
+    assert tuple(nat.knn_graph(p, p, 64)[0].shape) == (10, 64)          # k > 63: continuation rounds
 
 
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
@@ -481,3 +480,27 @@ def test_cfg4_slice_properties(nat):
         assert np.array_equal(kidx[r], order) and np.array_equal(kd[r], d[order])
         cols = np.where((d <= 2) & (d > 0))[0]
         assert np.array_equal(idx[indptr[r]:indptr[r + 1]], cols) and np.array_equal(w[indptr[r]:indptr[r + 1]], d[cols])
+
+
+def test_knn_beyond_63_neighbours(nat):
+    """k > 63 runs as continuation rounds (63 + 64 + ... ranks, each round restarts after the last
+    (distance, column) key): same canonical order as one stable sort, incl. ties, duplicates, k >= N."""
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    tok = synth.clustered_tokens(3000, 40, seed=5, members=500)
+    tok[10] = tok[2000]; tok[11] = tok[2000]
+    for bits in BITS:
+        p = _planes(nat, tok, bits)
+        for k in (64, 100, 127, 128, 200):
+            idx, d = nat.knn_graph(p, p, k)
+            ridx, rd = C.knn(tok, k)
+            assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd), (bits, k)
+        idx, d = nat.knn_graph(p, p, 150, row0=700, nrows=300)
+        ridx, rd = C.knn(tok, 150, row0=700, nrows=300)
+        assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
+    small = tok[:90]
+    p = _planes(nat, small, 5)
+    idx, d = nat.knn_graph(p, p, 130)                     # more ranks than sequences: -1 / 255 beyond N-1
+    ridx, rd = C.knn(small, 130)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
+    assert np.all(idx.cpu().numpy()[:, 89:] == -1)
