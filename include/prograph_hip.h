@@ -94,11 +94,13 @@ int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld
  * Replaces `torch.sum(X != Y[:,None,:], axis=2)` (prograph/distance/hamming.py:34;
  * K2+K3 of SURVEY.md §2.2).  out[m*ldo + n] = #{j : Y[m,j] != X[n,j]}, (M,N) like the
  * reference.  out_elem_bytes in {1,4,8} (uint8 / int32 / int64 = the reference's dtype).
+ * accumulate != 0 adds to `out` instead of overwriting it: sequences longer than one record
+ * (255 / 128 tokens) are handled as a sum over column segments packed separately.
  */
 int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad,
                      const void *y_planes, int64_t m, int64_t y_npad,
                      int l, int bits, void *out, int out_elem_bytes, int64_t ldo,
-                     void *stream);
+                     int accumulate, void *stream);
 
 /*
  * pg_eps_slots — the N^2 pass of the epsilon-neighbourhood graph.

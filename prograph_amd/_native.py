@@ -15,7 +15,8 @@ import numpy as np
 import torch   # must be imported before the library is loaded: see _load()
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprograph_hip.so")
+# PROGRAPH_HIP_LIB: load another build of the same ABI (kernel A/B comparisons, tools/ab.py)
+LIB_PATH = os.environ.get("PROGRAPH_HIP_LIB") or os.path.join(_HERE, "libprograph_hip.so")
 ABI_VERSION = 1
 
 BITS_5, BITS_8 = 5, 8
@@ -75,7 +76,7 @@ def _load():
         lib.pg_scan_scratch_bytes.argtypes = [_i64]
         lib.pg_device_info.argtypes = [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32]
         lib.pg_pack_planes.argtypes = [_vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _i64, _vp, _vp]
-        lib.pg_hamming_dense.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i64, _vp]
+        lib.pg_hamming_dense.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i64, _i32, _vp]
         lib.pg_eps_slots.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
                                      _vp, _vp, _vp, _vp]
         lib.pg_exclusive_scan.argtypes = [_vp, _i64, _vp, _vp, _vp]
@@ -209,13 +210,18 @@ def pack(tokens, rows=None, bits=None, width=None):
 _TORCH_OUT = {1: torch.uint8, 4: torch.int32, 8: torch.int64}
 
 
-def hamming_dense(xp, yp, out_bytes=8):
-    """(M, N) distance matrix of every row of `yp` against every row of `xp` (hamming.py:34)."""
+def hamming_dense(xp, yp, out_bytes=8, out=None):
+    """(M, N) distance matrix of every row of `yp` against every row of `xp` (hamming.py:34).
+    With `out` given the distances are ADDED to it (segment-wise sums for long sequences)."""
     if xp.g != yp.g or xp.bits != yp.bits:
         raise ValueError("operands must be packed with the same width and bit planes")
-    out = torch.empty((yp.n, xp.n), dtype=_TORCH_OUT[out_bytes], device=xp.buf.device)
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((yp.n, xp.n), dtype=_TORCH_OUT[out_bytes], device=xp.buf.device)
+    out_bytes = out.element_size()
     _check(lib().pg_hamming_dense(_ptr(xp.buf), xp.n, xp.npad, _ptr(yp.buf), yp.n, yp.npad, xp.g * 32, xp.bits,
-                                  _ptr(out), out_bytes, out.stride(0), _stream()), "pg_hamming_dense")
+                                  _ptr(out), out_bytes, out.stride(0), 1 if accumulate else 0, _stream()),
+           "pg_hamming_dense")
     return out
 
 

@@ -318,20 +318,38 @@ static const compact_fn kCompact[8] = {pg_launch_compact_g1, pg_launch_compact_g
                                        pg_launch_compact_g4, pg_launch_compact_g5, pg_launch_compact_g6,
                                        pg_launch_compact_g7, pg_launch_compact_g8};
 
-// Static, even split of the rows over the resident waves: every row costs the same (one
-// sweep over all columns), so equal row counts are equal work.  Each wave then walks its
-// rows in passes of at most PG_RB rows of nearly equal size.
+// Static, even split of the rows over the waves: every row costs the same (one sweep over all
+// columns), so equal row counts are equal work.  The kernel is VALU-issue bound and a workgroup
+// puts one wave on each SIMD of its CU, so the run time follows the busiest SIMD:
+//     makespan ~ (rows_per_wave + 1) * sum over rounds of t(waves in the round),
+//     n = ceil(workgroups / CUs) waves per SIMD run in rounds of 4 residents, t(4,1,2,3) = 4.3, 2.2, 3.1, 3.7
+// (the +1 is the per-wave cost of streaming the column tiles, ~1 row-equivalent; t(m) reflects
+// that m < 4 waves cannot keep the VALU issuing: one wave alone issues under half of the time.
+// Fitted to tools/sweep_rpw.py at N = 50k and 200k, within ~8 %).  rows_per_wave is chosen among
+// the multiples of 4 up to one pass (PG_RB) to minimise that; ties go to the larger value (fewer
+// column re-reads).  More than PG_RB rows per wave (only with the PG_WAVES_PER_CU /
+// PG_ROWS_PER_WAVE overrides) are walked in passes of nearly equal size.
 static int plan_rows(int64_t nrows, NsqParams *p, int *grid) {
   const int cus = cu_count();
   if (cus <= 0) return fail(PG_E_NODEV, "no HIP device");
-  // 32 waves per CU is the measured sweet spot at N = 200k (finer units balance the tail); a
-  // wave should still own >= 6 rows so that the column stream it re-reads is amortised
-  const long long maxWaves = (long long)cus * waves_per_cu();
-  long long rpw = (nrows + maxWaves - 1) / maxWaves;
-  const long long minRows = getenv("PG_WAVES_PER_CU") ? 1 : 6;
-  if (rpw < minRows) rpw = minRows;
-  // the filtered sweep takes rows four at a time: whole groups waste no stage-1 work
-  if (rpw >= 4) rpw = (rpw + 3) / 4 * 4;
+  long long rpw = 4;
+  if (getenv("PG_WAVES_PER_CU")) {
+    const long long maxWaves = (long long)cus * waves_per_cu();
+    rpw = (nrows + maxWaves - 1) / maxWaves;
+    if (rpw < 1) rpw = 1;
+    // the filtered sweep takes rows four at a time: whole groups waste no stage-1 work
+    if (rpw >= 4) rpw = (rpw + 3) / 4 * 4;
+  } else {
+    long long best = -1;
+    for (long long r = 4; r <= PG_RB; r += 4) {
+      const long long wgs = ((nrows + r - 1) / r + PG_WG_WAVES - 1) / PG_WG_WAVES;
+      const long long n = (wgs + cus - 1) / cus;             // waves the busiest SIMD runs, 4 at a time
+      static const long long kRound[4] = {43, 22, 31, 37};   // time of a round of 4 / 1 / 2 / 3 waves (x10)
+      const long long cost = ((n / 4) * kRound[0] + (n % 4 ? kRound[n % 4] : 0)) * (r + 1);
+      if (best < 0 || cost <= best) { best = cost; rpw = r; }
+    }
+  }
+  if (const char *e = getenv("PG_ROWS_PER_WAVE")) { if (atoi(e) > 0) rpw = atoi(e); }   // tuning sweeps
   const long long waves = (nrows + rpw - 1) / rpw;
   const long long passes = (rpw + PG_RB - 1) / PG_RB;
   p->rowsPerWave = (int)rpw;
@@ -375,7 +393,7 @@ int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld
 }
 
 int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad, const void *y_planes, int64_t m, int64_t y_npad,
-                     int l, int bits, void *out, int out_elem_bytes, int64_t ldo, void *stream) {
+                     int l, int bits, void *out, int out_elem_bytes, int64_t ldo, int accumulate, void *stream) {
   if (!x_planes || !y_planes || !out || n <= 0 || m <= 0 || ldo < n)
     return fail(PG_E_BADARG, "pg_hamming_dense: bad argument");
   if (int rc = check_bits(bits)) return rc;
@@ -387,7 +405,7 @@ int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad, const void
   DenseParams p;
   p.xPlanes = (const uint4 *)x_planes; p.xNpad = x_npad; p.n = n;
   p.yPlanes = (const uint4 *)y_planes; p.yNpad = y_npad; p.m = m;
-  p.out = out; p.ldo = ldo; p.outBytes = out_elem_bytes;
+  p.out = out; p.ldo = ldo; p.outBytes = out_elem_bytes; p.accumulate = accumulate ? 1 : 0;
   return launched(kDense[pg_ngroups(l) - 1](bits, p, (hipStream_t)stream), "pg_dense_kernel");
 }
 

@@ -186,6 +186,7 @@ struct DenseParams {
   void *out;
   long long ldo;
   int outBytes;
+  int accumulate;   // 1: out += distance (sequences longer than one record are summed segment by segment)
 };
 
 struct CompactParams {

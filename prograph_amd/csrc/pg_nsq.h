@@ -180,12 +180,21 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     auto sweep_filtered = [&](const uint4 (&c)[C][Q], long long t) -> int {
       const u32 col0 = (u32)(t * (64 * C)) + lane;
       int trig = 0;
-      uint4 r4[4];
+      // running LDS pointers (one v_add each per group instead of one address per read)
+      const uint4 *rp = rows;
+      const uint4 *bp = bnds;
+      // Two register sets (chunk 0 of four rows + their bounds) swap roles: while one group is
+      // evaluated the next one's LDS reads are in flight.
+      uint4 r4a[4], r4b[4];
+      uint4 bnda = make_uint4(p.hi1, p.hi1, p.hi1, p.hi1), bndb = bnda;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) r4[u] = rows[u * Q];
-      uint4 bnd = make_uint4(p.hi1, p.hi1, p.hi1, p.hi1);
-      if constexpr (MODE == PG_MODE_KNN) bnd = bnds[0];
-      for (int rr = 0; rr < nr; rr += 4) {
+      for (int u = 0; u < 4; ++u) r4a[u] = rp[u * Q];
+      if constexpr (MODE == PG_MODE_KNN) bnda = bp[0];
+      auto group = [&](const uint4 (&r4)[4], const uint4 &bnd, uint4 (&r4n)[4], uint4 &bndn, int rr) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r4n[u] = rp[(4 + u) * Q];
+        if constexpr (MODE == PG_MODE_KNN) bndn = bp[1];
+        __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads ahead of the arithmetic
         u64 m[4];
         const u32 bv[4] = {bnd.x, bnd.y, bnd.z, bnd.w};
         u32 lb[4][C];
@@ -198,10 +207,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
           for (int b = 1; b < C; ++b) lbmin = lbmin < lb[u][b] ? lbmin : lb[u][b];
           m[u] = __builtin_amdgcn_ballot_w64(lbmin < bv[u]);
         }
-        // next four rows' chunk 0 and bounds (rows of THIS group are not among them)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) r4[u] = rows[(rr + 4 + u) * Q];
-        if constexpr (MODE == PG_MODE_KNN) bnd = bnds[(rr >> 2) + 1];
         if (m[0] | m[1] | m[2] | m[3]) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
               ++trig;
               uint4 r[Q];
 #pragma unroll
-              for (int q = 0; q < Q; ++q) r[q] = rows[(rr + u) * Q + q];
+              for (int q = 0; q < Q; ++q) r[q] = rp[u * Q + q];
 #pragma unroll
               for (int b = 0; b < C; ++b) {
                 if (__builtin_amdgcn_ballot_w64(lb[u][b] < bv[u])) epilogue(M::dist(r, c[b], bias), col0 + b * 64, rr + u);
@@ -217,6 +222,12 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
             }
           }
         }
+        rp += 4 * Q;
+        bp += 1;
+      };
+      for (int rr = 0; rr < nr; rr += 8) {
+        group(r4a, bnda, r4b, bndb, rr);
+        if (rr + 4 < nr) group(r4b, bndb, r4a, bnda, rr + 4);
       }
       return trig;
     };
@@ -302,7 +313,10 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_dense_kernel(const DensePara
 #pragma unroll
     for (int q = 0; q < Q; ++q) r[q] = rows[rr * Q + q];
     const u32 d = mismatch<G, B>(r, c);
-    if (ok) out[(r0 + rr) * p.ldo + col] = (OutT)d;
+    if (ok) {
+      OutT *o = &out[(r0 + rr) * p.ldo + col];
+      *o = p.accumulate ? (OutT)(*o + (OutT)d) : (OutT)d;
+    }
   }
 }
 

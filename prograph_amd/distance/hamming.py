@@ -9,9 +9,11 @@ of X (the reference's docstring says N x M, its code and tests say M x N) — `t
 on the device of the inputs; `ValueError` on an empty operand; zero right-padding when the
 second dimensions differ; `similarity=True` returns 1/(1+d).
 
-Byte tokens (integer valued, 0..255, D <= 128) take the native kernel.  Anything else is not
-tokenised sequence data (floats with fractions, wide integers, D > 128) and is evaluated
-with the same torch expression as the reference, on the GPU; there is no CPU path.
+Byte tokens (integer valued, 0..255) take the native kernel at any D: one record holds 255
+tokens (5 bit planes) or 128 (8 planes); longer sequences are cut into column segments whose
+distances the kernel accumulates into the same (M, N) matrix.  Anything else is not tokenised
+sequence data (floats with fractions, wide integers) and is evaluated with the same torch
+expression as the reference, on the GPU; there is no CPU path.
 """
 import torch
 
@@ -30,7 +32,7 @@ def _x_entry(X, Xd, cacheable):
     key = (X.data_ptr(), tuple(X.shape), X.dtype, X._version, str(X.device)) if cacheable else None
     ent = _X_CACHE.get(key) if key is not None else None
     if ent is None:
-        xb = _as_byte_tokens(Xd) if X.shape[1] <= _native.MAX_L_5BIT else None
+        xb = _as_byte_tokens(Xd)
         ent = {"xb": xb, "max": int(xb.max()) if xb is not None else None, "planes": {}}
         if key is not None:
             if len(_X_CACHE) >= _X_CACHE_MAX:
@@ -39,10 +41,19 @@ def _x_entry(X, Xd, cacheable):
     return ent
 
 
-def _x_planes(ent, bits):
-    if bits not in ent["planes"]:
-        ent["planes"][bits] = _native.pack(ent["xb"], bits=bits)
-    return ent["planes"][bits]
+def _segments(d, bits):
+    w = _native.MAX_L_5BIT if bits == _native.BITS_5 else _native.MAX_L
+    if d <= w:
+        return [(0, d)]
+    w = w // 32 * 32                              # whole 32-token groups per segment
+    return [(a, min(d, a + w)) for a in range(0, d, w)]
+
+
+def _x_planes(ent, bits, seg):
+    key = (bits, seg)
+    if key not in ent["planes"]:
+        ent["planes"][key] = _native.pack(ent["xb"][:, seg[0]:seg[1]], bits=bits)
+    return ent["planes"][key]
 
 
 def _as_byte_tokens(T):
@@ -69,10 +80,10 @@ def hamming(X, Y, similarity=False):
     bits = None
     if yb is not None:
         bits = _native.BITS_5 if max(ent["max"], int(yb.max())) <= 31 else _native.BITS_8
-        if bits == _native.BITS_8 and X.shape[1] > _native.MAX_L:
-            yb = None                            # byte alphabets are native up to 128 tokens only
-    if yb is not None:
-        distances = _native.hamming_dense(_x_planes(ent, bits), _native.pack(yb, bits=bits), out_bytes=8)
+        distances = None
+        for seg in _segments(X.shape[1], bits):
+            distances = _native.hamming_dense(_x_planes(ent, bits, seg), _native.pack(yb[:, seg[0]:seg[1]], bits=bits),
+                                              out_bytes=8, out=distances)
     else:
         distances = torch.sum(Xd != Yd[:, None, :], axis=2)
     if similarity:

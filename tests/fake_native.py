@@ -54,9 +54,12 @@ def _pad_to(a, l):
     return out
 
 
-def _dense(xp, yp, out_bytes=8):
+def _dense(xp, yp, out_bytes=8, out=None):
     l = max(xp.l, yp.l)
     d = O.hamming(_pad_to(xp.tok, l), _pad_to(yp.tok, l))
+    if out is not None:
+        out += d.to(out.dtype)
+        return out
     return d.to({1: torch.uint8, 4: torch.int32, 8: torch.int64}[out_bytes])
 
 

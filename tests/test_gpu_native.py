@@ -452,6 +452,25 @@ def test_hamming_operator_cache_tracks_in_place_edits(nat):
     assert np.array_equal(hamming(X, Y).cpu().numpy(), O.hamming(Xh, Y.cpu().numpy()).numpy())
 
 
+@pytest.mark.parametrize("d,hi", [(256, 21), (700, 21), (129, 256), (300, 256), (1000, 256)])
+def test_hamming_operator_long_sequences(nat, d, hi):
+    """Sequences longer than one record: the operator sums the dense kernel over column segments
+    (accumulate mode of pg_hamming_dense) and must equal the reference expression bit for bit."""
+    from prograph_amd.distance import hamming
+    from oracle import prograph_oracle as O
+    rng = np.random.RandomState(d)
+    Xh = rng.randint(0, hi, size=(777, d)).astype(np.int64)
+    Xh[100:200] = Xh[0]                            # many small distances as well
+    Xh[100:200, ::7] = (Xh[100:200, ::7] + rng.randint(0, 2, size=Xh[100:200, ::7].shape)) % hi
+    Yh = Xh[rng.randint(0, 777, size=50)]
+    want = O.hamming(Xh, Yh).numpy()
+    got = hamming(torch.from_numpy(Xh).cuda(), torch.from_numpy(Yh).cuda())
+    assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want)
+    sim = hamming(torch.from_numpy(Xh).cuda(), torch.from_numpy(Yh[:, : d - 5]).cuda(), similarity=True)
+    Yp = np.concatenate([Yh[:, : d - 5], np.zeros((50, 5), dtype=np.int64)], axis=1)
+    assert np.array_equal(sim.cpu().numpy(), O.hamming(Xh, Yp, similarity=True).numpy())
+
+
 def test_cfg4_slice_properties(nat):
     """BASELINE.json configs[3] on one GPU: rank 3's row block (125 000 rows) of the N = 1 000 000,
     L = 64 problem against all columns, kNN k = 16 and eps <= 2.  Checked through sampled rows against
