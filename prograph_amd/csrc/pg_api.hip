@@ -428,7 +428,7 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
                  uint8_t *slot_w, uint32_t *counts, void *stream) {
   NsqParams p;
   if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits)) return rc;
-  if (!slot_idx || !slot_w || !counts || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
+  if (!slot_idx || !slot_w || !counts || cap < 0 || cap > PG_MAX_CAP || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
     return fail(PG_E_BADARG, "pg_eps_slots: bad argument");
   eps_interval(cmp, eps, &p.lo, &p.span);
   p.hi1 = (p.lo > 0xFFFFFF00u - 1u) ? 0u : p.lo + p.span + 1u;   // empty interval: nothing can match
@@ -539,7 +539,8 @@ int pg_lev_profile(const uint8_t *tokens, int64_t n, int l, int64_t ld, void *pr
 
 int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row0, int64_t nrows, int band, int cap,
                       int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts, void *stream) {
-  if (!profiles || !slot_idx || !slot_w || !counts || n <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > n || cap < 0)
+  if (!profiles || !slot_idx || !slot_w || !counts || n <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > n || cap < 0 ||
+      cap > PG_MAX_CAP)
     return fail(PG_E_BADARG, "pg_lev_candidates: bad argument");
   if (band < 0 || band > PG_LEV_MAX_BAND) return fail(PG_E_BADARG, "pg_lev_candidates: band must be in 0..8");
   if (npad < n || npad % 256) return fail(PG_E_BADARG, "pg_lev_candidates: bad npad");

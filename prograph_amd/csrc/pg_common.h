@@ -11,6 +11,8 @@ typedef unsigned long long u64;
 #define PG_WG_THREADS (PG_WAVE * PG_WG_WAVES)
 #define PG_RB 32    // rows per wave pass of the all-pairs engine (<= 64: per-row state is lane indexed)
 #define PG_RBD 64   // rows per workgroup of the dense kernel
+#define PG_RING 1024        // eps: entries of the per-wave LDS ring that parks matches (room for 4 rows x C x 64 kept free)
+#define PG_MAX_CAP (1 << 19)  // eps: slot positions are packed into 19 bits of the ring's meta word
 
 enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1 };
 
@@ -97,9 +99,9 @@ __device__ __forceinline__ u32 mismatch(const uint4 (&r)[Rec<G, B>::Q], const ui
 #define PG_LB_GROUPS 1
 #endif
 template <int G>
-__device__ __forceinline__ u32 mismatch_lb(const uint4 &r0, const uint4 &c0) {
+__device__ __forceinline__ u32 mismatch_lb(const uint4 &r0, const uint4 &c0, u32 seed) {
   constexpr int GL = G < PG_LB_GROUPS ? G : PG_LB_GROUPS;
-  u32 acc = __builtin_popcount(r0.x ^ c0.x);
+  u32 acc = __builtin_popcount(r0.x ^ c0.x) + seed;       // v_bcnt's addend carries the seed for free
   if constexpr (GL > 1) acc += __builtin_popcount(r0.y ^ c0.y);
   if constexpr (GL > 2) acc += __builtin_popcount(r0.z ^ c0.z);
   if constexpr (GL > 3) acc += __builtin_popcount(r0.w ^ c0.w);
@@ -114,7 +116,22 @@ struct HammingMetric {
   static __device__ __forceinline__ u32 dist(const uint4 (&r)[Q], const uint4 (&c)[Q], u32 init) {
     return mismatch<G, B>(r, c, init);
   }
-  static __device__ __forceinline__ u32 lower_bound(const uint4 &r0, const uint4 &c0) { return mismatch_lb<G>(r0, c0); }
+  // seed + (lower bound of the distance); the engine seeds with -bound and tests the sign
+  static __device__ __forceinline__ u32 lower_bound(const uint4 &r0, const uint4 &c0, u32 seed) {
+    return mismatch_lb<G>(r0, c0, seed);
+  }
+  // the same bound in two steps, so that the engine can issue the 2-cycle logic ops of a whole row
+  // group as one run and the 4-cycle popcounts as another (mixed streams run everything at the
+  // 4-cycle rate: tools/ubench/valu_s1.hip)
+  static __device__ __forceinline__ u32 lb_prep(const uint4 &r0, const uint4 &c0) { return r0.x ^ c0.x; }
+  static __device__ __forceinline__ u32 lb_finish(u32 x, const uint4 &r0, const uint4 &c0, u32 seed) {
+    constexpr int GL = G < PG_LB_GROUPS ? G : PG_LB_GROUPS;
+    u32 acc = __builtin_popcount(x) + seed;
+    if constexpr (GL > 1) acc += __builtin_popcount(r0.y ^ c0.y);
+    if constexpr (GL > 2) acc += __builtin_popcount(r0.z ^ c0.z);
+    if constexpr (GL > 3) acc += __builtin_popcount(r0.w ^ c0.w);
+    return acc;
+  }
 };
 
 // Edit-distance LOWER BOUND from the bag-of-symbols profile of a sequence (Levenshtein filter):
@@ -127,8 +144,12 @@ struct BagMetric {
   // stage-1 bound of the engine: the SAD over the first 16 symbols (chunk 0) already exceeds
   // 2*band for almost every unrelated pair: 4 v_sad_u8 instead of 9 + v_max
   static constexpr bool kHasLB = true;
-  static __device__ __forceinline__ u32 lower_bound(const uint4 &r0, const uint4 &c0) {
-    u32 s = __builtin_amdgcn_sad_u8(r0.x, c0.x, 0u);
+  static __device__ __forceinline__ u32 lb_prep(const uint4 &, const uint4 &) { return 0u; }
+  static __device__ __forceinline__ u32 lb_finish(u32, const uint4 &r0, const uint4 &c0, u32 seed) {
+    return lower_bound(r0, c0, seed);
+  }
+  static __device__ __forceinline__ u32 lower_bound(const uint4 &r0, const uint4 &c0, u32 seed) {
+    u32 s = __builtin_amdgcn_sad_u8(r0.x, c0.x, seed);
     s = __builtin_amdgcn_sad_u8(r0.y, c0.y, s);
     s = __builtin_amdgcn_sad_u8(r0.z, c0.z, s);
     return __builtin_amdgcn_sad_u8(r0.w, c0.w, s);

@@ -31,6 +31,12 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
   __shared__ uint4 rowbuf[PG_WG_WAVES][PG_RB + 4][Q];      // +4: the row prefetch runs up to four past
   __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
   __shared__ uint4 bndbuf[PG_WG_WAVES][PG_RB / 4 + 2];     // kNN: per row the current (k+1)-th distance
+  // eps: matches are parked in a wave-private LDS ring and written out in bursts.  A global store
+  // inside the tile loop would make the compiler drain vmcnt to 0 at every tile (loads and
+  // stores share the counter on gfx9), i.e. wait for the column prefetch it has just issued.
+  constexpr int RING = MODE == PG_MODE_EPS ? PG_RING : 1;
+  __shared__ u32 ringcol[PG_WG_WAVES][RING];
+  __shared__ u32 ringmeta[PG_WG_WAVES][RING];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     }
     if constexpr (MODE == PG_MODE_KNN) {
       for (int rr = 0; rr < nr; ++rr) lstbuf[wv][rr][lane] = 0xFFFFFFFFu;
-      if (lane < PG_RB + 8) bndw[lane] = 255u;               // open lists accept every distance
+      if (lane < PG_RB + 8) bndw[lane] = 0u - 255u;          // open lists accept every distance (stored negated)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -96,19 +102,44 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     // bias -lo rides in the popcount accumulator.  knn: keys are (distance << 24 | column); columns
     // only grow along the sweep, so a candidate beats the current (k+1)-th key iff its distance is
     // strictly smaller.
+    int nq = 0;                                             // ring fill, wave uniform
+    // The burst is written with inline-asm stores: the compiler's waitcnt pass does not see them,
+    // so its counted waits on the column prefetch survive (a visible store inside the tile loop
+    // turns every vmcnt(N) of the loop into vmcnt(0), explicit drain or not).  That is safe: the
+    // stores have no reader in this kernel, their operands are read at issue, and unseen extra
+    // entries in the in-order load queue can only make a counted wait stricter.
+    auto flush_ring = [&]() {
+      if constexpr (MODE == PG_MODE_EPS) {
+        for (int e = lane; e < nq; e += 64) {
+          const u32 meta = ringmeta[wv][e];
+          const u32 cval = ringcol[wv][e];
+          const long long o = (pr0 + (meta >> 27)) * (long long)p.cap + ((meta >> 8) & 0x7FFFFu);
+          int *pi = p.slotIdx + o;
+          unsigned char *pw = p.slotW + o;
+          asm volatile("global_store_dword %0, %1, off\n\tglobal_store_byte %2, %3, off"
+                       :
+                       : "v"(pi), "v"(cval), "v"(pw), "v"(meta)
+                       : "memory");
+        }
+        nq = 0;
+      }
+    };
     auto epilogue = [&](u32 d, u32 col, int rr) {
       if constexpr (MODE == PG_MODE_EPS) {
         const bool h2 = (d <= p.span) && (col < ncols);
         const u64 m2 = __builtin_amdgcn_ballot_w64(h2);
         if (m2) {
           const u32 cnt = __builtin_amdgcn_readlane(cntv, rr);
-          const u32 pos = cnt + mask_rank(m2);
-          if (h2 && pos < p.cap) {
-            const long long o = (pr0 + rr) * (long long)p.cap + pos;
-            p.slotIdx[o] = (int)col;
-            p.slotW[o] = (unsigned char)(d + p.lo);
+          const u32 rank = mask_rank(m2);
+          const u32 pos = cnt + rank;
+          if (h2 && pos < p.cap) {                          // the stored lanes are a prefix of the matching ones
+            ringcol[wv][nq + rank] = col;
+            ringmeta[wv][nq + rank] = ((u32)rr << 27) | (pos << 8) | (d + p.lo);
           }
-          cntv = (lane == rr) ? cnt + (u32)__popcll(m2) : cntv;
+          const u32 nm = (u32)__popcll(m2);
+          const u32 room = cnt < p.cap ? p.cap - cnt : 0u;
+          nq += (int)(nm < room ? nm : room);
+          cntv = (lane == rr) ? cnt + nm : cntv;
         }
       } else {
         u32 thr = __builtin_amdgcn_readlane(thrv, rr);
@@ -130,7 +161,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
           } while (m);
           lstbuf[wv][rr][lane] = lst;
           thrv = (lane == rr) ? thr : thrv;
-          if (lane == 0) bndw[rr] = thr >> 24;
+          if (lane == 0) bndw[rr] = 0u - (thr >> 24);
         }
       }
     };
@@ -167,6 +198,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
         ra = rows[(rr + 2) * Q];
         if (rr + 1 < nr) row_direct(c, rb, rr + 1, col0);
         rb = rows[(rr + 3) * Q];
+        if constexpr (MODE == PG_MODE_EPS) {
+          if (nq > RING - 4 * C * 64) flush_ring();
+        }
       }
     };
 
@@ -186,7 +220,12 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
       // Two register sets (chunk 0 of four rows + their bounds) swap roles: while one group is
       // evaluated the next one's LDS reads are in flight.
       uint4 r4a[4], r4b[4];
-      uint4 bnda = make_uint4(p.hi1, p.hi1, p.hi1, p.hi1), bndb = bnda;
+      // bounds travel NEGATED: they seed the popcount accumulator, so stage 1 yields lb - bound and
+      // "lb < bound" is the sign bit; the signs of a whole group are OR-ed with 2-cycle logic ops
+      // and examined with ONE v_cmp (v_min / v_cmp / v_bcnt are 4-cycle instructions on gfx950,
+      // xor / or / bitop3 take 2: tools/ubench/valu_ops.hip)
+      const u32 nhi = opaque_vgpr(0u - p.hi1);   // a VGPR, or hipcc splits the seeded popcount into bcnt + sub
+      uint4 bnda = make_uint4(nhi, nhi, nhi, nhi), bndb = bnda;
 #pragma unroll
       for (int u = 0; u < 4; ++u) r4a[u] = rp[u * Q];
       if constexpr (MODE == PG_MODE_KNN) bnda = bp[0];
@@ -195,35 +234,44 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
         for (int u = 0; u < 4; ++u) r4n[u] = rp[(4 + u) * Q];
         if constexpr (MODE == PG_MODE_KNN) bndn = bp[1];
         __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads ahead of the arithmetic
-        u64 m[4];
-        const u32 bv[4] = {bnd.x, bnd.y, bnd.z, bnd.w};
-        u32 lb[4][C];
+        const u32 nb[4] = {bnd.x, bnd.y, bnd.z, bnd.w};
+        u32 t[4][C], o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int b = 0; b < C; ++b) t[u][b] = M::lb_prep(r4[u], c[b][0]);
+        __builtin_amdgcn_sched_barrier(0);       // run of 2-cycle ops | run of 4-cycle ops
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int b = 0; b < C; ++b) t[u][b] = M::lb_finish(t[u][b], r4[u], c[b][0], nb[u]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+          o[u] = t[u][0];
 #pragma unroll
-          for (int b = 0; b < C; ++b) lb[u][b] = M::lower_bound(r4[u], c[b][0]);
-          u32 lbmin = lb[u][0];
-#pragma unroll
-          for (int b = 1; b < C; ++b) lbmin = lbmin < lb[u][b] ? lbmin : lb[u][b];
-          m[u] = __builtin_amdgcn_ballot_w64(lbmin < bv[u]);
+          for (int b = 1; b < C; ++b) o[u] |= t[u][b];
         }
-        if (m[0] | m[1] | m[2] | m[3]) {
+        if (__builtin_amdgcn_ballot_w64((int)((o[0] | o[1]) | (o[2] | o[3])) < 0)) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            if (m[u] && rr + u < nr) {
+            if (__builtin_amdgcn_ballot_w64((int)o[u] < 0) && rr + u < nr) {
               ++trig;
               uint4 r[Q];
 #pragma unroll
               for (int q = 0; q < Q; ++q) r[q] = rp[u * Q + q];
 #pragma unroll
               for (int b = 0; b < C; ++b) {
-                if (__builtin_amdgcn_ballot_w64(lb[u][b] < bv[u])) epilogue(M::dist(r, c[b], bias), col0 + b * 64, rr + u);
+                if (__builtin_amdgcn_ballot_w64((int)t[u][b] < 0)) epilogue(M::dist(r, c[b], bias), col0 + b * 64, rr + u);
               }
             }
           }
         }
         rp += 4 * Q;
         bp += 1;
+        if constexpr (MODE == PG_MODE_EPS) {
+          if (nq > RING - 4 * C * 64) flush_ring();        // room for the next group's worst case
+        }
       };
       for (int rr = 0; rr < nr; rr += 8) {
         group(r4a, bnda, r4b, bndb, rr);
@@ -266,6 +314,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 
     // ---- per-row results of this pass ----
     if constexpr (MODE == PG_MODE_EPS) {
+      flush_ring();
       if (lane < nr) p.counts[pr0 + lane] = cntv;
     } else {
       for (int rr = 0; rr < nr; ++rr) {
