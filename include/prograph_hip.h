@@ -49,7 +49,6 @@ extern "C" {
 #define PG_MAX_L_5BIT 255          /* tokens per sequence, 5 bit planes (distance fits uint8) */
 #define PG_MAX_N_KNN  16777216     /* 2^24                                               */
 #define PG_MAX_K      63           /* k+1 sorted keys live in the 64 lanes of one VGPR   */
-#define PG_MAX_CAP (1 << 19)      /* slot capacity per row of pg_eps_slots / pg_lev_candidates */
 #define PG_LEV_MAX_BAND 8          /* banded Levenshtein keeps 2*8+1 diagonals in registers */
 
 /* bit planes per token: fixed when a matrix is packed, passed to every call that reads it */
@@ -111,7 +110,6 @@ int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad,
  * For every row the matching column indices are written in ascending order into the
  * row's slot (capacity `cap`), and the exact number of matches into counts[] even when
  * it exceeds `cap` (pg_eps_compact recomputes such rows).
- * 0 <= cap <= PG_MAX_CAP (2^19).
  *   cmp, eps   PG_CMP_* and the threshold; pairs with d == 0 are always excluded
  *   slot_idx   int32 [nrows*cap], slot_w uint8 [nrows*cap], counts uint32 [nrows]
  */

@@ -310,6 +310,19 @@ static void eps_interval(int cmp, double eps, u32 *lo, u32 *span) {
 typedef int (*nsq_fn)(int, int, const NsqParams &, int, hipStream_t);
 typedef int (*dense_fn)(int, const DenseParams &, hipStream_t);
 typedef int (*compact_fn)(int, const CompactParams &, hipStream_t);
+typedef int (*occ_fn)(int, int);
+static const occ_fn kNsqOcc[8] = {pg_occ_nsq_g1, pg_occ_nsq_g2, pg_occ_nsq_g3, pg_occ_nsq_g4,
+                                  pg_occ_nsq_g5, pg_occ_nsq_g6, pg_occ_nsq_g7, pg_occ_nsq_g8};
+// resident waves per SIMD (= workgroups per CU) of an engine instance, asked once from the runtime
+static int nsq_occupancy(int groups, int mode, int bits) {
+  static int cache[8][2][2];
+  int &c = cache[groups - 1][mode == PG_MODE_KNN][bits == 8];
+  if (c == 0) {
+    const int n = kNsqOcc[groups - 1](mode, bits);
+    c = n < 1 ? 4 : (n > 8 ? 8 : n);
+  }
+  return c;
+}
 static const nsq_fn kNsq[8] = {pg_launch_nsq_g1, pg_launch_nsq_g2, pg_launch_nsq_g3, pg_launch_nsq_g4,
                                pg_launch_nsq_g5, pg_launch_nsq_g6, pg_launch_nsq_g7, pg_launch_nsq_g8};
 static const dense_fn kDense[8] = {pg_launch_dense_g1, pg_launch_dense_g2, pg_launch_dense_g3, pg_launch_dense_g4,
@@ -321,15 +334,16 @@ static const compact_fn kCompact[8] = {pg_launch_compact_g1, pg_launch_compact_g
 // Static, even split of the rows over the waves: every row costs the same (one sweep over all
 // columns), so equal row counts are equal work.  The kernel is VALU-issue bound and a workgroup
 // puts one wave on each SIMD of its CU, so the run time follows the busiest SIMD:
-//     makespan ~ (rows_per_wave + 1) * sum over rounds of t(waves in the round),
-//     n = ceil(workgroups / CUs) waves per SIMD run in rounds of 4 residents, t(4,1,2,3) = 4.3, 2.2, 3.1, 3.7
-// (the +1 is the per-wave cost of streaming the column tiles, ~1 row-equivalent; t(m) reflects
-// that m < 4 waves cannot keep the VALU issuing: one wave alone issues under half of the time.
-// Fitted to tools/sweep_rpw.py at N = 50k and 200k, within ~8 %).  rows_per_wave is chosen among
-// the multiples of 4 up to one pass (PG_RB) to minimise that; ties go to the larger value (fewer
-// column re-reads).  More than PG_RB rows per wave (only with the PG_WAVES_PER_CU /
+//     makespan ~ (rows_per_wave + 1) * sum over rounds of T(waves in the round),
+//     n = ceil(workgroups / CUs) waves per SIMD run in rounds of `occ` residents (the instance's
+//     occupancy), T(1..8) = 2.2, 3.1, 3.7, 4.3, 5.1, 6, 7, 8
+// (the +1 is the per-wave cost of streaming the column tiles, ~1 row-equivalent; T(m) reflects
+// that fewer than ~5 waves cannot keep the VALU issuing: one wave alone issues under half of the
+// time.  Fitted to tools/sweep_rpw.py at N = 50k and 200k, within ~8 %).  rows_per_wave is chosen
+// among the multiples of 4 up to one pass (PG_RB) to minimise that; ties go to the larger value
+// (fewer column re-reads).  More than PG_RB rows per wave (only with the PG_WAVES_PER_CU /
 // PG_ROWS_PER_WAVE overrides) are walked in passes of nearly equal size.
-static int plan_rows(int64_t nrows, NsqParams *p, int *grid) {
+static int plan_rows(int64_t nrows, NsqParams *p, int *grid, int occ) {
   const int cus = cu_count();
   if (cus <= 0) return fail(PG_E_NODEV, "no HIP device");
   long long rpw = 4;
@@ -340,17 +354,20 @@ static int plan_rows(int64_t nrows, NsqParams *p, int *grid) {
     // the filtered sweep takes rows four at a time: whole groups waste no stage-1 work
     if (rpw >= 4) rpw = (rpw + 3) / 4 * 4;
   } else {
+    static const long long kRound[9] = {0, 22, 31, 37, 43, 51, 60, 70, 80};   // T(m) x 10
+    if (occ < 1) occ = 1;
+    if (occ > 8) occ = 8;
     long long best = -1;
     for (long long r = 4; r <= PG_RB; r += 4) {
       const long long wgs = ((nrows + r - 1) / r + PG_WG_WAVES - 1) / PG_WG_WAVES;
-      const long long n = (wgs + cus - 1) / cus;             // waves the busiest SIMD runs, 4 at a time
-      static const long long kRound[4] = {43, 22, 31, 37};   // time of a round of 4 / 1 / 2 / 3 waves (x10)
-      const long long cost = ((n / 4) * kRound[0] + (n % 4 ? kRound[n % 4] : 0)) * (r + 1);
+      const long long n = (wgs + cus - 1) / cus;             // waves the busiest SIMD runs
+      const long long cost = ((n / occ) * kRound[occ] + kRound[n % occ]) * (r + 1);
       if (best < 0 || cost <= best) { best = cost; rpw = r; }
     }
   }
   if (const char *e = getenv("PG_ROWS_PER_WAVE")) { if (atoi(e) > 0) rpw = atoi(e); }   // tuning sweeps
   const long long waves = (nrows + rpw - 1) / rpw;
+  if (getenv("PG_DEBUG_PLAN")) fprintf(stderr, "[pg plan] rows=%lld occ=%d rows_per_wave=%lld waves=%lld\n", (long long)nrows, occ, rpw, waves);
   const long long passes = (rpw + PG_RB - 1) / PG_RB;
   p->rowsPerWave = (int)rpw;
   long long rpp = (rpw + passes - 1) / passes;
@@ -428,13 +445,13 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
                  uint8_t *slot_w, uint32_t *counts, void *stream) {
   NsqParams p;
   if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits)) return rc;
-  if (!slot_idx || !slot_w || !counts || cap < 0 || cap > PG_MAX_CAP || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
+  if (!slot_idx || !slot_w || !counts || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
     return fail(PG_E_BADARG, "pg_eps_slots: bad argument");
   eps_interval(cmp, eps, &p.lo, &p.span);
   p.hi1 = (p.lo > 0xFFFFFF00u - 1u) ? 0u : p.lo + p.span + 1u;   // empty interval: nothing can match
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
   int grid = 0;
-  if (int rc = plan_rows(nrows, &p, &grid)) return rc;
+  if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS, bits))) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(eps)");
 }
 
@@ -483,7 +500,7 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   p.k = k; p.knnFirst = first; p.floorKeys = floor_keys; p.lastKeys = last_keys;
   p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;
-  if (int rc = plan_rows(nrows, &p, &grid)) return rc;
+  if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits))) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");
 }
 
@@ -539,8 +556,7 @@ int pg_lev_profile(const uint8_t *tokens, int64_t n, int l, int64_t ld, void *pr
 
 int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row0, int64_t nrows, int band, int cap,
                       int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts, void *stream) {
-  if (!profiles || !slot_idx || !slot_w || !counts || n <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > n || cap < 0 ||
-      cap > PG_MAX_CAP)
+  if (!profiles || !slot_idx || !slot_w || !counts || n <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > n || cap < 0)
     return fail(PG_E_BADARG, "pg_lev_candidates: bad argument");
   if (band < 0 || band > PG_LEV_MAX_BAND) return fail(PG_E_BADARG, "pg_lev_candidates: band must be in 0..8");
   if (npad < n || npad % 256) return fail(PG_E_BADARG, "pg_lev_candidates: bad npad");
@@ -553,7 +569,9 @@ int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row
   p.filter = lb_filter_mode();             // keep pairs with max(SAD, 2*|dlen|) <= 2*band, self included
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
   int grid = 0;
-  if (int rc = plan_rows(nrows, &p, &grid)) return rc;
+  static int bag_occ = 0;
+  if (!bag_occ) { bag_occ = pg_occ_nsq_bag(); if (bag_occ < 1) bag_occ = 4; }
+  if (int rc = plan_rows(nrows, &p, &grid, bag_occ)) return rc;
   return launched(pg_launch_nsq_bag(p, grid, (hipStream_t)stream), "pg_nsq_kernel(bag)");
 }
 

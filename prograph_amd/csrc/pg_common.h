@@ -11,8 +11,6 @@ typedef unsigned long long u64;
 #define PG_WG_THREADS (PG_WAVE * PG_WG_WAVES)
 #define PG_RB 32    // rows per wave pass of the all-pairs engine (<= 64: per-row state is lane indexed)
 #define PG_RBD 64   // rows per workgroup of the dense kernel
-#define PG_RING 1024        // eps: entries of the per-wave LDS ring that parks matches (room for 4 rows x C x 64 kept free)
-#define PG_MAX_CAP (1 << 19)  // eps: slot positions are packed into 19 bits of the ring's meta word
 
 enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1 };
 
@@ -220,10 +218,12 @@ struct CompactParams {
 // per-(G,B) launchers (pg_nsq_inst.hip is compiled once per group count G = 1..4)
 #define PG_DECL_G(G)                                                                          \
   int pg_launch_nsq_g##G(int mode, int bits, const NsqParams &p, int grid, hipStream_t s);   \
+  int pg_occ_nsq_g##G(int mode, int bits); /* resident workgroups per CU of that instance */ \
   int pg_launch_dense_g##G(int bits, const DenseParams &p, hipStream_t s);                    \
   int pg_launch_compact_g##G(int bits, const CompactParams &p, hipStream_t s);
 PG_DECL_G(1) PG_DECL_G(2) PG_DECL_G(3) PG_DECL_G(4) PG_DECL_G(5) PG_DECL_G(6) PG_DECL_G(7) PG_DECL_G(8)
 int pg_launch_nsq_bag(const NsqParams &p, int grid, hipStream_t s);   // pg_lev.hip
+int pg_occ_nsq_bag();
 int pg_launch_lev_profile(const unsigned char *tok, long long n, int l, long long ld, u32 *prof, long long npad,
                           int *lens, u32 *flags, hipStream_t s);
 int pg_launch_lev_select(const unsigned char *tok, long long n, int l, long long ld, const uint4 *planes,

@@ -22,6 +22,14 @@
 #define PG_LEV_MAXL 128
 #define PG_LEV_W 17          // diagonals kept: band <= 8
 
+int pg_occ_nsq_bag() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pg_nsq_kernel<BagMetric, 2, PG_MODE_EPS>, PG_WG_THREADS, 0) !=
+      hipSuccess)
+    n = 0;
+  return n;
+}
+
 int pg_launch_nsq_bag(const NsqParams &p, int grid, hipStream_t s) {
   pg_nsq_kernel<BagMetric, 2, PG_MODE_EPS><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
   return (int)hipGetLastError();

@@ -31,12 +31,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
   __shared__ uint4 rowbuf[PG_WG_WAVES][PG_RB + 4][Q];      // +4: the row prefetch runs up to four past
   __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
   __shared__ uint4 bndbuf[PG_WG_WAVES][PG_RB / 4 + 2];     // kNN: per row the current (k+1)-th distance
-  // eps: matches are parked in a wave-private LDS ring and written out in bursts.  A global store
-  // inside the tile loop would make the compiler drain vmcnt to 0 at every tile (loads and
-  // stores share the counter on gfx9), i.e. wait for the column prefetch it has just issued.
-  constexpr int RING = MODE == PG_MODE_EPS ? PG_RING : 1;
-  __shared__ u32 ringcol[PG_WG_WAVES][RING];
-  __shared__ u32 ringmeta[PG_WG_WAVES][RING];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
@@ -102,44 +96,19 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     // bias -lo rides in the popcount accumulator.  knn: keys are (distance << 24 | column); columns
     // only grow along the sweep, so a candidate beats the current (k+1)-th key iff its distance is
     // strictly smaller.
-    int nq = 0;                                             // ring fill, wave uniform
-    // The burst is written with inline-asm stores: the compiler's waitcnt pass does not see them,
-    // so its counted waits on the column prefetch survive (a visible store inside the tile loop
-    // turns every vmcnt(N) of the loop into vmcnt(0), explicit drain or not).  That is safe: the
-    // stores have no reader in this kernel, their operands are read at issue, and unseen extra
-    // entries in the in-order load queue can only make a counted wait stricter.
-    auto flush_ring = [&]() {
-      if constexpr (MODE == PG_MODE_EPS) {
-        for (int e = lane; e < nq; e += 64) {
-          const u32 meta = ringmeta[wv][e];
-          const u32 cval = ringcol[wv][e];
-          const long long o = (pr0 + (meta >> 27)) * (long long)p.cap + ((meta >> 8) & 0x7FFFFu);
-          int *pi = p.slotIdx + o;
-          unsigned char *pw = p.slotW + o;
-          asm volatile("global_store_dword %0, %1, off\n\tglobal_store_byte %2, %3, off"
-                       :
-                       : "v"(pi), "v"(cval), "v"(pw), "v"(meta)
-                       : "memory");
-        }
-        nq = 0;
-      }
-    };
     auto epilogue = [&](u32 d, u32 col, int rr) {
       if constexpr (MODE == PG_MODE_EPS) {
         const bool h2 = (d <= p.span) && (col < ncols);
         const u64 m2 = __builtin_amdgcn_ballot_w64(h2);
         if (m2) {
           const u32 cnt = __builtin_amdgcn_readlane(cntv, rr);
-          const u32 rank = mask_rank(m2);
-          const u32 pos = cnt + rank;
-          if (h2 && pos < p.cap) {                          // the stored lanes are a prefix of the matching ones
-            ringcol[wv][nq + rank] = col;
-            ringmeta[wv][nq + rank] = ((u32)rr << 27) | (pos << 8) | (d + p.lo);
+          const u32 pos = cnt + mask_rank(m2);
+          if (h2 && pos < p.cap) {
+            const long long o = (pr0 + rr) * (long long)p.cap + pos;
+            p.slotIdx[o] = (int)col;
+            p.slotW[o] = (unsigned char)(d + p.lo);
           }
-          const u32 nm = (u32)__popcll(m2);
-          const u32 room = cnt < p.cap ? p.cap - cnt : 0u;
-          nq += (int)(nm < room ? nm : room);
-          cntv = (lane == rr) ? cnt + nm : cntv;
+          cntv = (lane == rr) ? cnt + (u32)__popcll(m2) : cntv;
         }
       } else {
         u32 thr = __builtin_amdgcn_readlane(thrv, rr);
@@ -198,9 +167,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
         ra = rows[(rr + 2) * Q];
         if (rr + 1 < nr) row_direct(c, rb, rr + 1, col0);
         rb = rows[(rr + 3) * Q];
-        if constexpr (MODE == PG_MODE_EPS) {
-          if (nq > RING - 4 * C * 64) flush_ring();
-        }
       }
     };
 
@@ -269,9 +235,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
         }
         rp += 4 * Q;
         bp += 1;
-        if constexpr (MODE == PG_MODE_EPS) {
-          if (nq > RING - 4 * C * 64) flush_ring();        // room for the next group's worst case
-        }
       };
       for (int rr = 0; rr < nr; rr += 8) {
         group(r4a, bnda, r4b, bndb, rr);
@@ -314,7 +277,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 
     // ---- per-row results of this pass ----
     if constexpr (MODE == PG_MODE_EPS) {
-      flush_ring();
       if (lane < nr) p.counts[pr0 + lane] = cntv;
     } else {
       for (int rr = 0; rr < nr; ++rr) {

@@ -8,9 +8,11 @@
 #endif
 
 #ifndef PG_CSEL
-// measured (N = 200k, L = 64): C = 2 keeps the kernel at 113 VGPRs = 4 waves per SIMD and beats
-// C = 4 (167 VGPRs, 3 waves) by 10-15 %; the stage-1 cost per pair is the same for both
-#define PG_CSEL(Q) ((Q) <= 6 ? 2 : 1)
+// measured: at Q <= 4 chunks per record (L <= 96 with 5 planes, L <= 64 with 8) two columns per lane
+// keep the kernel at 4 waves per SIMD and win (C = 4 at L = 64: 167 VGPRs, 3 waves, 10-15 % slower);
+// from Q = 5 on (L = 128: two register sets of 2 x 5 chunks leave 2 waves per SIMD) one column per
+// lane is 22 % faster (N = 100k, L = 128: 6.43 -> 5.00 ms)
+#define PG_CSEL(Q) ((Q) <= 4 ? 2 : 1)
 #endif
 #define PG_CAT_(a, b) a##b
 #define PG_CAT(a, b) PG_CAT_(a, b)
@@ -32,6 +34,22 @@ static int launch_nsq(const NsqParams &p, int grid, hipStream_t s) {
   } else {
     return (int)hipErrorInvalidValue;
   }
+}
+
+template <int B, int MODE>
+static int occ_nsq() {
+  int n = 0;
+  if constexpr (Cols<B>::kBuilt) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pg_nsq_kernel<HammingMetric<PG_G, B>, Cols<B>::C, MODE>,
+                                                     PG_WG_THREADS, 0) != hipSuccess)
+      n = 0;
+  }
+  return n;
+}
+
+int PG_CAT(pg_occ_nsq_g, PG_G)(int mode, int bits) {
+  if (mode == PG_MODE_EPS) return bits == 5 ? occ_nsq<5, PG_MODE_EPS>() : occ_nsq<8, PG_MODE_EPS>();
+  return bits == 5 ? occ_nsq<5, PG_MODE_KNN>() : occ_nsq<8, PG_MODE_KNN>();
 }
 
 int PG_CAT(pg_launch_nsq_g, PG_G)(int mode, int bits, const NsqParams &p, int grid, hipStream_t s) {

@@ -8,6 +8,7 @@ import sys, os
 sys.path.insert(0, %r)
 import numpy as np, torch
 from prograph_amd import _native as nat, synth
+CASES = eval(os.environ.get("AB_CASES", "None"))
 def run(N, L, bits, mode, iters=7):
     tok = synth.clustered_tokens(N, L)
     p = nat.pack(torch.from_numpy(tok), bits=bits)
@@ -22,7 +23,7 @@ def run(N, L, bits, mode, iters=7):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return float(np.median(ts))
-cases = [(200000, 64, 5, "knn"), (200000, 64, 5, "eps"), (50000, 32, 5, "knn"), (200000, 64, 8, "knn"), (100000, 128, 5, "knn")]
+cases = CASES or [(200000, 64, 5, "knn"), (200000, 64, 5, "eps"), (50000, 32, 5, "knn"), (50000, 32, 5, "eps"), (200000, 64, 8, "knn"), (100000, 128, 5, "knn")]
 print(" ".join("%%s%%d/%%d/%%d=%%.3f" %% (m, N, L, b, run(N, L, b, m)) for N, L, b, m in cases), flush=True)
 """ % ROOT
 

@@ -27,7 +27,10 @@ def run(N, L, mode, rpws, iters=5):
     print(f"N={N} L={L} {mode}: " + "  ".join(f"rpw{w}={t:.3f}" for w, t in res), flush=True)
 
 
-rp = [0, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64]
-run(200000, 64, "knn", rp); run(200000, 64, "eps", rp)
-run(50000, 32, "knn", rp[:9]); run(50000, 32, "eps", rp[:9])
-run(125000, 64, "knn", rp)
+rp = [0, 4, 8, 12, 16, 20, 24, 28, 32]
+if len(sys.argv) > 1 and sys.argv[1] == "small":
+    run(50000, 32, "eps", rp); run(50000, 32, "knn", rp); run(20000, 32, "eps", rp); run(100000, 64, "eps", rp)
+else:
+    run(200000, 64, "knn", rp); run(200000, 64, "eps", rp)
+    run(50000, 32, "knn", rp); run(50000, 32, "eps", rp)
+    run(125000, 64, "knn", rp)
