@@ -343,7 +343,7 @@ static const compact_fn kCompact[8] = {pg_launch_compact_g1, pg_launch_compact_g
 // among the multiples of 4 up to one pass (PG_RB) to minimise that; ties go to the larger value
 // (fewer column re-reads).  More than PG_RB rows per wave (only with the PG_WAVES_PER_CU /
 // PG_ROWS_PER_WAVE overrides) are walked in passes of nearly equal size.
-static int plan_rows(int64_t nrows, NsqParams *p, int *grid, int occ) {
+static int plan_rows(int64_t nrows, NsqParams *p, int *grid, int occ, int maxRows = PG_RB) {
   const int cus = cu_count();
   if (cus <= 0) return fail(PG_E_NODEV, "no HIP device");
   long long rpw = 4;
@@ -358,7 +358,7 @@ static int plan_rows(int64_t nrows, NsqParams *p, int *grid, int occ) {
     if (occ < 1) occ = 1;
     if (occ > 8) occ = 8;
     long long best = -1;
-    for (long long r = 4; r <= PG_RB; r += 4) {
+    for (long long r = 4; r <= maxRows; r += 4) {
       const long long wgs = ((nrows + r - 1) / r + PG_WG_WAVES - 1) / PG_WG_WAVES;
       const long long n = (wgs + cus - 1) / cus;             // waves the busiest SIMD runs
       const long long cost = ((n / occ) * kRound[occ] + kRound[n % occ]) * (r + 1);
@@ -368,11 +368,11 @@ static int plan_rows(int64_t nrows, NsqParams *p, int *grid, int occ) {
   if (const char *e = getenv("PG_ROWS_PER_WAVE")) { if (atoi(e) > 0) rpw = atoi(e); }   // tuning sweeps
   const long long waves = (nrows + rpw - 1) / rpw;
   if (getenv("PG_DEBUG_PLAN")) fprintf(stderr, "[pg plan] rows=%lld occ=%d rows_per_wave=%lld waves=%lld\n", (long long)nrows, occ, rpw, waves);
-  const long long passes = (rpw + PG_RB - 1) / PG_RB;
+  const long long passes = (rpw + maxRows - 1) / maxRows;
   p->rowsPerWave = (int)rpw;
   long long rpp = (rpw + passes - 1) / passes;
   if (rpp >= 4) rpp = (rpp + 3) / 4 * 4;
-  if (rpp > PG_RB) rpp = PG_RB;
+  if (rpp > maxRows) rpp = maxRows;
   p->rowsPerPass = (int)rpp;
   *grid = (int)((waves + PG_WG_WAVES - 1) / PG_WG_WAVES);
   return 0;
@@ -500,7 +500,7 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   p.k = k; p.knnFirst = first; p.floorKeys = floor_keys; p.lastKeys = last_keys;
   p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;
-  if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits))) return rc;
+  if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits), PG_RB_KNN)) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");
 }
 

@@ -10,6 +10,9 @@ typedef unsigned long long u64;
 #define PG_WG_WAVES 4
 #define PG_WG_THREADS (PG_WAVE * PG_WG_WAVES)
 #define PG_RB 32    // rows per wave pass of the all-pairs engine (<= 64: per-row state is lane indexed)
+#define PG_RB_KNN 28 // kNN passes: 28 rows, so that lists + candidate queue keep 4 workgroups per CU in LDS
+#define PG_QCAP 128  // kNN: entries of the per-wave candidate queue (flushed in batches of 64)
+#define PG_PUSH_MAX 8 // kNN: a triggered sub-tile with more passing lanes than this is evaluated in place
 #define PG_RBD 64   // rows per workgroup of the dense kernel
 
 enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1 };
@@ -117,6 +120,23 @@ struct HammingMetric {
   // seed + (lower bound of the distance); the engine seeds with -bound and tests the sign
   static __device__ __forceinline__ u32 lower_bound(const uint4 &r0, const uint4 &c0, u32 seed) {
     return mismatch_lb<G>(r0, c0, seed);
+  }
+  // exact distance with both records GATHERED per lane (each lane its own row and column): the
+  // deferred-candidate path of the kNN engine.  rowrec = the row's record in LDS (dword p*G+g),
+  // colw = the chunk-major plane buffer viewed as dwords.
+  static __device__ __forceinline__ u32 dist_gather(const u32 *rowrec, const u32 *colw, long long npad, u32 col) {
+    u32 acc = 0;
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+      u32 t = 0;
+#pragma unroll
+      for (int pl = 0; pl < B; ++pl) {
+        const int i = pl * G + g;
+        t |= rowrec[i] ^ colw[((long long)(i >> 2) * npad + col) * 4 + (i & 3)];
+      }
+      acc += __builtin_popcount(t);
+    }
+    return acc;
   }
   // the same bound in two steps, so that the engine can issue the 2-cycle logic ops of a whole row
   // group as one run and the 4-cycle popcounts as another (mixed streams run everything at the

@@ -27,10 +27,13 @@
 template <class M, int C, int MODE>
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
-  constexpr int LROWS = MODE == PG_MODE_KNN ? PG_RB : 1;
-  __shared__ uint4 rowbuf[PG_WG_WAVES][PG_RB + 4][Q];      // +4: the row prefetch runs up to four past
+  constexpr int RB = MODE == PG_MODE_KNN ? PG_RB_KNN : PG_RB;   // rows per pass
+  constexpr int LROWS = MODE == PG_MODE_KNN ? RB : 1;
+  constexpr int QCAP = MODE == PG_MODE_KNN ? PG_QCAP : 1;
+  __shared__ uint4 rowbuf[PG_WG_WAVES][RB + 4][Q];         // +4: the row prefetch runs up to four past
   __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
-  __shared__ uint4 bndbuf[PG_WG_WAVES][PG_RB / 4 + 2];     // kNN: per row the current (k+1)-th distance
+  __shared__ uint4 bndbuf[PG_WG_WAVES][RB / 4 + 2];        // kNN: per row minus the current (k+1)-th distance
+  __shared__ u32 cqbuf[PG_WG_WAVES][QCAP];                 // kNN: deferred candidates (row << 24 | column)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
@@ -53,15 +56,15 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 
     // ---- stage this pass's rows into the wave's LDS region (wave private: LDS operations
     // of one wave are processed in order, the fences only pin the compiler) ----
-    for (int e = lane; e < (PG_RB + 4) * Q; e += 64) {
-      const int rr = e % (PG_RB + 4), q = e / (PG_RB + 4);
+    for (int e = lane; e < (RB + 4) * Q; e += 64) {
+      const int rr = e % (RB + 4), q = e / (RB + 4);
       uint4 v = make_uint4(0, 0, 0, 0);
       if (rr < nr) v = p.rowPlanes[(long long)q * p.rowNpad + p.row0 + pr0 + rr];
       rowbuf[wv][rr][q] = v;
     }
     if constexpr (MODE == PG_MODE_KNN) {
       for (int rr = 0; rr < nr; ++rr) lstbuf[wv][rr][lane] = 0xFFFFFFFFu;
-      if (lane < PG_RB + 8) bndw[lane] = 0u - 255u;          // open lists accept every distance (stored negated)
+      if (lane < RB + 8) bndw[lane] = 0u - 255u;             // open lists accept every distance (stored negated)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -132,6 +135,59 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
           thrv = (lane == rr) ? thr : thrv;
           if (lane == 0) bndw[rr] = 0u - (thr >> 24);
         }
+      }
+    };
+
+    // kNN, filtered sweep: a triggered sub-tile usually holds ONE lane worth an exact distance (a
+    // cluster mate that passes the plane-0 bound).  Evaluating it in place spends a full wave on it
+    // (~23 VALU per trigger); instead the passing lanes are queued as (row, column) and 64 queued
+    // candidates are evaluated together, one per lane, with both records gathered (row from the
+    // wave's LDS, column from L2).  Keys are totally ordered, so insertion order does not matter for
+    // the lists; the in-place test "d < current distance" stays exact because every list entry,
+    // queued or not, has a smaller column than the sweep position.  Until a queued candidate is
+    // inserted the row's bound is merely looser than it could be.
+    int qn = 0;                                             // queue fill, wave uniform
+    auto flush_batch = [&]() {
+      if constexpr (MODE == PG_MODE_KNN) {
+        const int nbat = qn < 64 ? qn : 64;
+        const u32 e = cqbuf[wv][lane];
+        const u32 col = e & 0x00FFFFFFu;
+        const u32 erow = (e >> 24) & 31u;
+        const bool act = lane < nbat && col < ncols;
+        u32 key = 0xFFFFFFFFu, thr = 0u;
+        if (act) {
+          uint4 cr[Q], rw[Q];                             // all gathers in flight at once
+#pragma unroll
+          for (int q = 0; q < Q; ++q) cr[q] = colp[(long long)q * p.colNpad + col];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) rw[q] = rowbuf[wv][erow][q];
+          const u32 d = M::dist(rw, cr, 0u);
+          key = (d << 24) | col;
+          thr = lstbuf[wv][erow][thrLane];
+        }
+        const bool cand = act && key < thr;
+        u64 m = __builtin_amdgcn_ballot_w64(cand);
+        while (m) {
+          const int j = __builtin_ctzll(m);
+          m &= m - 1;
+          const int row = (int)__builtin_amdgcn_readlane(erow, j);
+          const u32 x = __builtin_amdgcn_readlane(key, j);
+          if (p.floorKeys && x <= __builtin_amdgcn_readlane(floorv, row)) continue;   // continuation round
+          u32 lst = lstbuf[wv][row][lane];
+          if (x < __builtin_amdgcn_readlane(lst, thrLane)) {
+            const u32 prev = wave_shr1(lst, 0u);
+            lst = (lst <= x) ? lst : (prev > x ? prev : x);
+            lstbuf[wv][row][lane] = lst;
+            const u32 nthr = __builtin_amdgcn_readlane(lst, thrLane);
+            thrv = (lane == row) ? nthr : thrv;
+            if (lane == 0) bndw[row] = 0u - (nthr >> 24);
+          }
+        }
+        if (qn > 64) {                                       // keep the tail (at most 63 entries)
+          const u32 tail = cqbuf[wv][64 + lane];
+          cqbuf[wv][lane] = tail;
+        }
+        qn -= nbat;
       }
     };
 
@@ -223,14 +279,28 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
           for (int u = 0; u < 4; ++u) {
             if (__builtin_amdgcn_ballot_w64((int)o[u] < 0) && rr + u < nr) {
               ++trig;
-              uint4 r[Q];
-#pragma unroll
-              for (int q = 0; q < Q; ++q) r[q] = rp[u * Q + q];
 #pragma unroll
               for (int b = 0; b < C; ++b) {
-                if (__builtin_amdgcn_ballot_w64((int)t[u][b] < 0)) epilogue(M::dist(r, c[b], bias), col0 + b * 64, rr + u);
+                const bool hit = (int)t[u][b] < 0;
+                const u64 mb = __builtin_amdgcn_ballot_w64(hit);
+                if (!mb) continue;
+                if constexpr (MODE == PG_MODE_KNN) {
+                  const int npass = __popcll(mb);
+                  if (npass <= PG_PUSH_MAX) {               // few lanes: queue them
+                    if (hit) cqbuf[wv][qn + mask_rank(mb)] = ((u32)(rr + u) << 24) | (col0 + b * 64);
+                    qn += npass;
+                    continue;
+                  }
+                }
+                uint4 r[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) r[q] = rp[u * Q + q];
+                epilogue(M::dist(r, c[b], bias), col0 + b * 64, rr + u);
               }
             }
+          }
+          if constexpr (MODE == PG_MODE_KNN) {
+            if (qn >= 64) flush_batch();                    // at most 4*C*PUSH_MAX = 64 pushes per group
           }
         }
         rp += 4 * Q;
@@ -275,6 +345,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
       }
     }
 
+    if constexpr (MODE == PG_MODE_KNN) {
+      while (qn > 0) flush_batch();
+    }
     // ---- per-row results of this pass ----
     if constexpr (MODE == PG_MODE_EPS) {
       if (lane < nr) p.counts[pr0 + lane] = cntv;
