@@ -343,7 +343,13 @@ static const compact_fn kCompact[8] = {pg_launch_compact_g1, pg_launch_compact_g
 // among the multiples of 4 up to one pass (PG_RB) to minimise that; ties go to the larger value
 // (fewer column re-reads).  More than PG_RB rows per wave (only with the PG_WAVES_PER_CU /
 // PG_ROWS_PER_WAVE overrides) are walked in passes of nearly equal size.
-static int plan_rows(int64_t nrows, NsqParams *p, int *grid, int occ, int maxRows = PG_RB) {
+// Second term: every wave streams the whole column matrix (ncols * Q * 16 bytes).  While that fits
+// the L2s the stream is hidden; beyond (cfg4: 48 MB) the sweep becomes bound by L2-miss traffic
+// served from the Infinity Cache: measured 11.5-15 TB/s aggregate at 48 MB, ~18-20 at 24 MB
+// (tools/sweep_rpw_big.py; N = 1M, 125k rows: 16 rows per wave 28.8 ms, 24 rows 20.5 ms).  The plan
+// minimises max(VALU makespan, streamed bytes / bandwidth) with bandwidth = 13 TB/s * (48 MB / bytes)^0.65
+// (capped at 4x) and 1.21e-11 s per makespan unit and column.
+static int plan_rows(int64_t nrows, NsqParams *p, int *grid, int occ, double recBytes, int maxRows = PG_RB) {
   const int cus = cu_count();
   if (cus <= 0) return fail(PG_E_NODEV, "no HIP device");
   long long rpw = 4;
@@ -357,12 +363,18 @@ static int plan_rows(int64_t nrows, NsqParams *p, int *grid, int occ, int maxRow
     static const long long kRound[9] = {0, 22, 31, 37, 43, 51, 60, 70, 80};   // T(m) x 10
     if (occ < 1) occ = 1;
     if (occ > 8) occ = 8;
-    long long best = -1;
+    const double matBytes = recBytes * (double)p->ncols;
+    double bw = 13e12;
+    if (matBytes > 0 && matBytes < 48e6) bw *= fmin(4.0, pow(48e6 / matBytes, 0.65));
+    double best = -1;
     for (long long r = 4; r <= maxRows; r += 4) {
-      const long long wgs = ((nrows + r - 1) / r + PG_WG_WAVES - 1) / PG_WG_WAVES;
+      const long long nw = (nrows + r - 1) / r;
+      const long long wgs = (nw + PG_WG_WAVES - 1) / PG_WG_WAVES;
       const long long n = (wgs + cus - 1) / cus;             // waves the busiest SIMD runs
-      const long long cost = ((n / occ) * kRound[occ] + kRound[n % occ]) * (r + 1);
-      if (best < 0 || cost <= best) { best = cost; rpw = r; }
+      const double valu = 1.21e-11 * (double)(((n / occ) * kRound[occ] + kRound[n % occ]) * (r + 1));
+      const double stream = (double)nw * recBytes / bw;      // both per column
+      const double cost = valu > stream ? valu : stream;
+      if (best < 0 || cost <= best * 1.0000001) { best = cost; rpw = r; }
     }
   }
   if (const char *e = getenv("PG_ROWS_PER_WAVE")) { if (atoi(e) > 0) rpw = atoi(e); }   // tuning sweeps
@@ -451,7 +463,7 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
   p.hi1 = (p.lo > 0xFFFFFF00u - 1u) ? 0u : p.lo + p.span + 1u;   // empty interval: nothing can match
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
   int grid = 0;
-  if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS, bits))) return rc;
+  if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS, bits), 16.0 * pg_nchunks(l, bits))) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(eps)");
 }
 
@@ -500,7 +512,7 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   p.k = k; p.knnFirst = first; p.floorKeys = floor_keys; p.lastKeys = last_keys;
   p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;
-  if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits), PG_RB_KNN)) return rc;
+  if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits), 16.0 * pg_nchunks(l, bits), PG_RB_KNN)) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");
 }
 
@@ -571,7 +583,7 @@ int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row
   int grid = 0;
   static int bag_occ = 0;
   if (!bag_occ) { bag_occ = pg_occ_nsq_bag(); if (bag_occ < 1) bag_occ = 4; }
-  if (int rc = plan_rows(nrows, &p, &grid, bag_occ)) return rc;
+  if (int rc = plan_rows(nrows, &p, &grid, bag_occ, 48.0)) return rc;
   return launched(pg_launch_nsq_bag(p, grid, (hipStream_t)stream), "pg_nsq_kernel(bag)");
 }
 

@@ -121,23 +121,6 @@ struct HammingMetric {
   static __device__ __forceinline__ u32 lower_bound(const uint4 &r0, const uint4 &c0, u32 seed) {
     return mismatch_lb<G>(r0, c0, seed);
   }
-  // exact distance with both records GATHERED per lane (each lane its own row and column): the
-  // deferred-candidate path of the kNN engine.  rowrec = the row's record in LDS (dword p*G+g),
-  // colw = the chunk-major plane buffer viewed as dwords.
-  static __device__ __forceinline__ u32 dist_gather(const u32 *rowrec, const u32 *colw, long long npad, u32 col) {
-    u32 acc = 0;
-#pragma unroll 1
-    for (int g = 0; g < G; ++g) {
-      u32 t = 0;
-#pragma unroll
-      for (int pl = 0; pl < B; ++pl) {
-        const int i = pl * G + g;
-        t |= rowrec[i] ^ colw[((long long)(i >> 2) * npad + col) * 4 + (i & 3)];
-      }
-      acc += __builtin_popcount(t);
-    }
-    return acc;
-  }
   // the same bound in two steps, so that the engine can issue the 2-cycle logic ops of a whole row
   // group as one run and the 4-cycle popcounts as another (mixed streams run everything at the
   // 4-cycle rate: tools/ubench/valu_s1.hip)

@@ -285,7 +285,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
                 const u64 mb = __builtin_amdgcn_ballot_w64(hit);
                 if (!mb) continue;
                 if constexpr (MODE == PG_MODE_KNN) {
-                  const int npass = __popcll(mb);
+                  // two 32-bit popcounts: a 64-bit one makes hipcc compare in 64 bits on the VALU
+                  const int npass = __builtin_popcount((u32)mb) + __builtin_popcount((u32)(mb >> 32));
                   if (npass <= PG_PUSH_MAX) {               // few lanes: queue them
                     if (hit) cqbuf[wv][qn + mask_rank(mb)] = ((u32)(rr + u) << 24) | (col0 + b * 64);
                     qn += npass;
