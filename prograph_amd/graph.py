@@ -41,12 +41,13 @@ class CSRGraph:
 
     def to_tuples(self):
         """list of N (np.int64 indices ascending, weights) — the reference's `Neighbours` format.
-        Rows without neighbours get `(array([], int), array([], int))` (prograph.py:753)."""
+        Rows without neighbours get `(array([], int), array([], int))` (prograph.py:753); all such rows
+        share ONE pair of zero-length arrays (nothing can be written into them), the others are
+        views into the two host arrays."""
         indptr, idx, w = self.host()
-        out = []
-        for a, b in zip(indptr[:-1].tolist(), indptr[1:].tolist()):
-            out.append((idx[a:b], w[a:b]) if b > a else (np.array([], dtype=int), np.array([], dtype=int)))
-        return out
+        nothing = (np.array([], dtype=int), np.array([], dtype=int))
+        a, b = indptr[:-1].tolist(), indptr[1:].tolist()
+        return [(idx[i:j], w[i:j]) if j > i else nothing for i, j in zip(a, b)]
 
     def _w(self, boolean_weights):
         if boolean_weights:
