@@ -268,13 +268,29 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 #pragma unroll
           for (int b = 0; b < C; ++b) t[u][b] = M::lb_finish(t[u][b], r4[u], c[b][0], nb[u]);
         __builtin_amdgcn_sched_barrier(0);
+        // OR of all 4*C signs with three-input ors (4 instructions for 8 values; every VALU
+        // instruction of this mixed stream costs about the same, so fewer is better)
+        u32 any = t[0][0];
+        if constexpr (C == 2) {
+          // (asm: hipcc would otherwise rebuild the reduction from the per-row ors of the slow path)
+          u32 a1, a2;
+          asm("v_or3_b32 %0, %1, %2, %3" : "=v"(a1) : "v"(t[0][0]), "v"(t[0][1]), "v"(t[1][0]));
+          asm("v_or3_b32 %0, %1, %2, %3" : "=v"(a2) : "v"(t[1][1]), "v"(t[2][0]), "v"(t[2][1]));
+          asm("v_or3_b32 %0, %1, %2, %3" : "=v"(a1) : "v"(a1), "v"(t[3][0]), "v"(t[3][1]));
+          any = a1 | a2;
+        } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          o[u] = t[u][0];
+          for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int b = 1; b < C; ++b) o[u] |= t[u][b];
+            for (int b = 0; b < C; ++b) any |= t[u][b];
         }
-        if (__builtin_amdgcn_ballot_w64((int)((o[0] | o[1]) | (o[2] | o[3])) < 0)) {
+        if (__builtin_amdgcn_ballot_w64((int)any < 0)) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            o[u] = t[u][0];
+#pragma unroll
+            for (int b = 1; b < C; ++b) o[u] |= t[u][b];
+          }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             if (__builtin_amdgcn_ballot_w64((int)o[u] < 0) && rr + u < nr) {
