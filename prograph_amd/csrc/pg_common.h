@@ -12,6 +12,7 @@ typedef unsigned long long u64;
 #define PG_RB 32    // rows per wave pass of the all-pairs engine (<= 64: per-row state is lane indexed)
 #define PG_RB_KNN 28 // kNN passes: 28 rows, so that lists + candidate queue keep 4 workgroups per CU in LDS
 #define PG_QCAP 128  // kNN: entries of the per-wave candidate queue (flushed in batches of 64)
+#define PG_QCAP_EPS 576 // eps: every passing lane is queued (order!), a group can add 4 rows x 2 x 64
 #define PG_PUSH_MAX 8 // kNN: a triggered sub-tile with more passing lanes than this is evaluated in place
 #define PG_RBD 64   // rows per workgroup of the dense kernel
 

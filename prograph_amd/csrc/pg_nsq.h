@@ -29,11 +29,11 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
   constexpr int Q = M::Q;
   constexpr int RB = MODE == PG_MODE_KNN ? PG_RB_KNN : PG_RB;   // rows per pass
   constexpr int LROWS = MODE == PG_MODE_KNN ? RB : 1;
-  constexpr int QCAP = MODE == PG_MODE_KNN ? PG_QCAP : 1;
+  constexpr int QCAP = MODE == PG_MODE_KNN ? PG_QCAP : (M::kHasLB ? PG_QCAP_EPS : 1);
   __shared__ uint4 rowbuf[PG_WG_WAVES][RB + 4][Q];         // +4: the row prefetch runs up to four past
   __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
   __shared__ uint4 bndbuf[PG_WG_WAVES][RB / 4 + 2];        // kNN: per row minus the current (k+1)-th distance
-  __shared__ u32 cqbuf[PG_WG_WAVES][QCAP];                 // kNN: deferred candidates (row << 24 | column)
+  __shared__ u32 cqbuf[PG_WG_WAVES][QCAP];                 // deferred candidates: kNN row << 24 | column, eps {row, column} pairs
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
@@ -191,6 +191,48 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
       }
     };
 
+    // eps, filtered sweep: the same deferral.  Every passing lane is queued (never evaluated in
+    // place: slot positions are handed out in queue order, which is ascending column order per
+    // row), the queue is drained before a direct-form tile and at the end of the pass.  Needs the
+    // column index in 27 bits; wider problems keep the in-place path.
+    const bool deferEps = MODE == PG_MODE_EPS && M::kHasLB && p.ncols < (1ll << 27);
+    auto flush_eps = [&]() {
+      if constexpr (MODE == PG_MODE_EPS && M::kHasLB) {
+        const int nbat = qn < 64 ? qn : 64;
+        const u32 e = cqbuf[wv][lane];
+        const u32 col = e & 0x07FFFFFFu;
+        const u32 erow = e >> 27;
+        const bool act = lane < nbat && col < ncols;
+        u32 d = 0xFFFFFFFFu;
+        if (act) {
+          uint4 cr[Q], rw[Q];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) cr[q] = colp[(long long)q * p.colNpad + col];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) rw[q] = rowbuf[wv][erow][q];
+          d = M::dist(rw, cr, bias);
+        }
+        const bool match = act && d <= p.span;
+        u64 m = __builtin_amdgcn_ballot_w64(match);
+        while (m) {                                          // one turn per row present in the batch
+          const u32 row = __builtin_amdgcn_readlane(erow, __builtin_ctzll(m));
+          const bool mine = match && erow == row;
+          const u64 same = __builtin_amdgcn_ballot_w64(mine);
+          const u32 cnt = __builtin_amdgcn_readlane(cntv, (int)row);
+          const u32 pos = cnt + mask_rank(same);
+          if (mine && pos < p.cap) {
+            const long long o = (pr0 + row) * (long long)p.cap + pos;
+            p.slotIdx[o] = (int)col;
+            p.slotW[o] = (unsigned char)(d + p.lo);
+          }
+          cntv = (lane == (int)row) ? cnt + (u32)__popcll(same) : cntv;
+          m &= ~same;
+        }
+        for (int i = lane; i + 64 < qn; i += 64) cqbuf[wv][i] = cqbuf[wv][i + 64];   // keep the tail, in order
+        qn -= nbat;
+      }
+    };
+
     // Direct form of one row-step: all C exact distances, one min + compare + branch.  Chunk 0 of
     // the row arrives prefetched, the remaining chunks are read here (keeping only chunk 0 in the
     // double buffer holds the kernel at 3 waves per SIMD; buffering whole rows costs a wave).
@@ -300,11 +342,17 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
                 const bool hit = (int)t[u][b] < 0;
                 const u64 mb = __builtin_amdgcn_ballot_w64(hit);
                 if (!mb) continue;
+                // two 32-bit popcounts: a 64-bit one makes hipcc compare in 64 bits on the VALU
+                const int npass = __builtin_popcount((u32)mb) + __builtin_popcount((u32)(mb >> 32));
                 if constexpr (MODE == PG_MODE_KNN) {
-                  // two 32-bit popcounts: a 64-bit one makes hipcc compare in 64 bits on the VALU
-                  const int npass = __builtin_popcount((u32)mb) + __builtin_popcount((u32)(mb >> 32));
                   if (npass <= PG_PUSH_MAX) {               // few lanes: queue them
                     if (hit) cqbuf[wv][qn + mask_rank(mb)] = ((u32)(rr + u) << 24) | (col0 + b * 64);
+                    qn += npass;
+                    continue;
+                  }
+                } else if constexpr (M::kHasLB) {
+                  if (deferEps) {                           // always queued: slots follow queue order
+                    if (hit) cqbuf[wv][qn + mask_rank(mb)] = ((u32)(rr + u) << 27) | (col0 + b * 64);
                     qn += npass;
                     continue;
                   }
@@ -318,6 +366,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
           }
           if constexpr (MODE == PG_MODE_KNN) {
             if (qn >= 64) flush_batch();                    // at most 4*C*PUSH_MAX = 64 pushes per group
+          } else if constexpr (M::kHasLB) {
+            while (qn >= 64) flush_eps();                   // at most 4*C*64 pushes per group
           }
         }
         rp += 4 * Q;
@@ -348,6 +398,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
           return;
         }
         if (direct_left > 0) --direct_left;
+        if constexpr (MODE == PG_MODE_EPS) {
+          while (qn > 0) flush_eps();                       // in-place stores must come after queued ones
+        }
       }
       sweep_direct(c, t);
     };
@@ -364,6 +417,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
 
     if constexpr (MODE == PG_MODE_KNN) {
       while (qn > 0) flush_batch();
+    } else {
+      while (qn > 0) flush_eps();
     }
     // ---- per-row results of this pass ----
     if constexpr (MODE == PG_MODE_EPS) {
