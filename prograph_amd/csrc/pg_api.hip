@@ -510,6 +510,9 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   if (k < 1 || first < 0 || first > 1 || first + k > 64) return fail(PG_E_BADARG, "pg_knn_hamming: k out of range");
   if (ncols > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_knn_hamming: ncols exceeds 2^24");
   p.k = k; p.knnFirst = first; p.floorKeys = floor_keys; p.lastKeys = last_keys;
+  // optimistic stage-1 cap (pg_nsq.h): 8 = half of what unrelated sequences show in the plane-0 bound
+  p.knnGuess = getenv("PG_KNN_GUESS") ? (u32)atoi(getenv("PG_KNN_GUESS")) : 8u;
+  if (p.filter == 0) p.knnGuess = 0;                       // no stage 1, nothing to cap
   p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;
   if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits), 16.0 * pg_nchunks(l, bits), PG_RB_KNN)) return rc;

@@ -186,6 +186,7 @@ struct NsqParams {
   long long colNpad, ncols;
   int rowsPerWave, rowsPerPass;
   int filter;   // 1 = plane-0 lower-bound filter allowed (adaptive per tile), 0 = always direct
+  u32 knnGuess; // kNN: optimistic cap on the stage-1 bound until a row's list is full (0 = off), see pg_nsq.h
   // eps
   u32 lo, span, cap;
   u32 hi1;      // lo + span + 1 (saturating): a pair whose lower bound reaches it cannot match

@@ -25,7 +25,9 @@
 #include <type_traits>
 
 template <class M, int C, int MODE>
-__global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p) {
+// kNN instances with two columns per lane are held at 4 (records of <= 3 chunks) / 3 waves per SIMD
+__global__ __launch_bounds__(PG_WG_THREADS)
+__attribute__((amdgpu_waves_per_eu((MODE == PG_MODE_KNN && C == 2) ? (M::Q <= 3 ? 4 : 3) : 1, 8))) void pg_nsq_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
   constexpr int RB = MODE == PG_MODE_KNN ? PG_RB_KNN : PG_RB;   // rows per pass
   constexpr int LROWS = MODE == PG_MODE_KNN ? RB : 1;
@@ -33,6 +35,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
   __shared__ uint4 rowbuf[PG_WG_WAVES][RB + 4][Q];         // +4: the row prefetch runs up to four past
   __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
   __shared__ uint4 bndbuf[PG_WG_WAVES][RB / 4 + 2];        // kNN: per row minus the current (k+1)-th distance
+  __shared__ u32 capbuf[PG_WG_WAVES][MODE == PG_MODE_KNN ? RB + 4 : 1];   // kNN: per row cap on the published bound
   __shared__ u32 cqbuf[PG_WG_WAVES][QCAP];                 // deferred candidates: kNN row << 24 | column, eps {row, column} pairs
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
   const long long wr0 = gw * p.rowsPerWave;
   if (wr0 >= p.nrows) return;   // whole wave leaves; no workgroup barrier is used below
   const long long wr1 = (wr0 + p.rowsPerWave < p.nrows) ? wr0 + p.rowsPerWave : p.nrows;
-  const long long ntiles = (p.ncols + 64 * C - 1) / (64 * C);
+  const int ntiles = (int)((p.ncols + 64 * C - 1) / (64 * C));   // ncols < 2^31
   const uint4 *__restrict__ colp = p.colPlanes;
   const u32 ncols = (u32)p.ncols;
   const uint4 *rows = &rowbuf[wv][0][0] + opaque_zero();   // broadcast reads, kept "divergent"
@@ -62,9 +65,23 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
       if (rr < nr) v = p.rowPlanes[(long long)q * p.rowNpad + p.row0 + pr0 + rr];
       rowbuf[wv][rr][q] = v;
     }
+    // kNN, optimistic start: until a row has seen k+1 near columns its threshold is useless (any
+    // unrelated pair passes) and the sweep would have to run in the direct form (~8 % of the tiles,
+    // ~20 % of the instructions at cfg3).  Instead the published stage-1 bound is capped at G0 while
+    // the row is "optimistic": only columns whose lower bound is below G0 are looked at.  That is
+    // exact for every row whose final (k+1)-th distance is below G0 (a skipped column has
+    // d >= lb >= G0).  At a checkpoint after 1/8 of the tiles the rows that are not there yet lose
+    // the cap, and the tiles before the checkpoint are swept again for them at the end (phase 1)
+    // with the relaxed rule "lb <= distance bound, full key comparison, no duplicates": the list
+    // then holds columns from everywhere, so ties can no longer be decided by sweep position.
+    const u32 G0 = (MODE == PG_MODE_KNN && M::kHasLB) ? p.knnGuess : 0u;   // the host passes 0 when the filter is off
+    u32 failed = 0;                                         // kNN: rows that lost their optimistic cap (bit = row); bit 31 = phase 1
+#define resweep (failed >> 31)
+    int tredo = 0;                                          // kNN: tiles [0, tredo) are swept again for them
     if constexpr (MODE == PG_MODE_KNN) {
       for (int rr = 0; rr < nr; ++rr) lstbuf[wv][rr][lane] = 0xFFFFFFFFu;
-      if (lane < RB + 8) bndw[lane] = 0u - 255u;             // open lists accept every distance (stored negated)
+      if (lane < RB + 8) bndw[lane] = 0u - (G0 ? G0 : 255u);   // bounds are stored negated
+      if (lane < RB + 4) capbuf[wv][lane] = G0 ? G0 : 255u;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -86,7 +103,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     // two so the sets swap roles instead of being copied, and the prefetch is unconditional (the
     // last tile re-reads itself) so that the waitcnt pass leaves it in flight across the rows.
     uint4 ca[C][Q], cb[C][Q];
-    auto load_tile = [&](uint4 (&dst)[C][Q], long long t) {
+    auto load_tile = [&](uint4 (&dst)[C][Q], int t) {
       const long long tt = t < ntiles ? t : ntiles - 1;
 #pragma unroll
       for (int b = 0; b < C; ++b)
@@ -99,6 +116,14 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     // bias -lo rides in the popcount accumulator.  knn: keys are (distance << 24 | column); columns
     // only grow along the sweep, so a candidate beats the current (k+1)-th key iff its distance is
     // strictly smaller.
+    // stage-1 bound of a row after its threshold moved: min(distance bound, cap), negated
+    auto publish = [&](int row, u32 thr) {
+      if (lane == 0) {
+        const u32 cp = capbuf[wv][row];
+        const u32 b = (thr >> 24) + (u32)resweep;           // phase 1: lb <= distance bound may still win a tie
+        bndw[row] = 0u - (b < cp ? b : cp);
+      }
+    };
     auto epilogue = [&](u32 d, u32 col, int rr) {
       if constexpr (MODE == PG_MODE_EPS) {
         const bool h2 = (d <= p.span) && (col < ncols);
@@ -116,7 +141,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
       } else {
         u32 thr = __builtin_amdgcn_readlane(thrv, rr);
         const u32 key = (d << 24) | col;
-        bool cand = (d < (thr >> 24)) && (col < ncols);
+        // full key comparison: along the forward sweep it equals "d < current distance" (every list
+        // entry has a smaller column), in phase 1 it also decides ties against later columns
+        bool cand = (key < thr) && (col < ncols);
         if (p.floorKeys) cand = cand && key > __builtin_amdgcn_readlane(floorv, rr);   // continuation round
         u64 m = __builtin_amdgcn_ballot_w64(cand);
         if (m) {
@@ -125,7 +152,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
             const int j = __builtin_ctzll(m);
             m &= m - 1;
             const u32 x = __builtin_amdgcn_readlane(key, j);
-            if (x < thr) {
+            if (x < thr && !(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
               const u32 prev = wave_shr1(lst, 0u);
               lst = (lst <= x) ? lst : (prev > x ? prev : x);
               thr = __builtin_amdgcn_readlane(lst, thrLane);
@@ -133,7 +160,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
           } while (m);
           lstbuf[wv][rr][lane] = lst;
           thrv = (lane == rr) ? thr : thrv;
-          if (lane == 0) bndw[rr] = 0u - (thr >> 24);
+          publish(rr, thr);
         }
       }
     };
@@ -174,13 +201,13 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
           const u32 x = __builtin_amdgcn_readlane(key, j);
           if (p.floorKeys && x <= __builtin_amdgcn_readlane(floorv, row)) continue;   // continuation round
           u32 lst = lstbuf[wv][row][lane];
-          if (x < __builtin_amdgcn_readlane(lst, thrLane)) {
+          if (x < __builtin_amdgcn_readlane(lst, thrLane) && !(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
             const u32 prev = wave_shr1(lst, 0u);
             lst = (lst <= x) ? lst : (prev > x ? prev : x);
             lstbuf[wv][row][lane] = lst;
             const u32 nthr = __builtin_amdgcn_readlane(lst, thrLane);
             thrv = (lane == row) ? nthr : thrv;
-            if (lane == 0) bndw[row] = 0u - (nthr >> 24);
+            publish(row, nthr);
           }
         }
         if (qn > 64) {                                       // keep the tail (at most 63 entries)
@@ -257,7 +284,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     // One tile against the pass's rows, direct form: the row loop is unrolled by two with two
     // static chunk-0 buffers refilled (broadcast ds_read_b128) right after their last use.  Rows
     // nr.. exist in the buffer as zeros, so trailing prefetches are harmless.
-    auto sweep_direct = [&](const uint4 (&c)[C][Q], long long t) {
+    auto sweep_direct = [&](const uint4 (&c)[C][Q], int t) {
       const u32 col0 = (u32)(t * (64 * C)) + lane;
       uint4 ra = rows[0], rb = rows[Q];
       for (int rr = 0; rr < nr; rr += 2) {
@@ -275,7 +302,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     // VALU busy at 3 waves per SIMD: the serial tail (ballot -> branch) is paid once per 4 rows.
     // kNN bounds come from LDS (one broadcast ds_read_b128 = the four rows' current (k+1)-th
     // distances, written by the slow path), eps uses the constant hi+1.
-    auto sweep_filtered = [&](const uint4 (&c)[C][Q], long long t) -> int {
+    auto sweep_filtered = [&](const uint4 (&c)[C][Q], int t) -> int {
       const u32 col0 = (u32)(t * (64 * C)) + lane;
       int trig = 0;
       // running LDS pointers (one v_add each per group instead of one address per read)
@@ -386,8 +413,12 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     // that fails, 120 tiles run direct before the filter is probed again (probing a dense data set
     // costs ~2 %).  Wave uniform throughout.
     int win_tiles = 0, win_trig = 0, direct_left = 0;
-    auto sweep = [&](const uint4 (&c)[C][Q], long long t) {
+    auto sweep = [&](const uint4 (&c)[C][Q], int t) {
       if constexpr (M::kHasLB) {
+        if (resweep) {                                        // phase 1 stays filtered: frozen rows never trigger there,
+          sweep_filtered(c, t);                               // the direct form would evaluate them again
+          return;
+        }
         if (p.filter != 0 && direct_left == 0) {
           win_trig += sweep_filtered(c, t);
           if (++win_tiles == 8) {
@@ -405,13 +436,53 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
       sweep_direct(c, t);
     };
 
-    load_tile(ca, 0);
-    for (long long t = 0; t < ntiles; t += 2) {
-      load_tile(cb, t + 1);
-      sweep(ca, t);
-      if (t + 1 < ntiles) {
-        load_tile(ca, t + 2);
-        sweep(cb, t + 1);
+    // checkpoints (first tile after them): after 1/32 of the tiles a row without any near column yet
+    // (nearest needed rank at distance >= G0) is taken to be unclustered and loses the cap; after
+    // 1/8 every row whose list is not settled below G0 does.  Phase 1 covers the larger range in use.
+    auto checkpoint = [&](int tnext) {
+      if constexpr (MODE == PG_MODE_KNN) {
+        const int tsw1 = (ntiles + 31) >> 5, tsw2 = (ntiles + 7) >> 3;
+        if (G0 && !resweep && (tnext == tsw1 || tnext == tsw2)) {
+          while (qn > 0) flush_batch();
+          const bool mine = lane < nr && !((failed >> lane) & 1);
+          u32 dref = thrv >> 24;                               // open lists read 255
+          if (tnext != tsw2) dref = mine ? lstbuf[wv][lane][p.knnFirst] >> 24 : 0u;
+          const bool late = mine && dref >= G0;
+          const u32 now = (u32)__builtin_amdgcn_ballot_w64(late);   // rows < 32
+          if (now) {
+            failed |= now;
+            tredo = tnext;
+            if (late) {
+              capbuf[wv][lane] = 255u;
+              bndw[lane] = 0u - (thrv >> 24);
+            }
+          }
+        }
+      }
+    };
+    int tend = ntiles;
+    for (;;) {
+      load_tile(ca, 0);
+      for (int t = 0; t < tend; t += 2) {
+        load_tile(cb, t + 1);
+        sweep(ca, t);
+        checkpoint(t + 1);
+        if (t + 1 < tend) {
+          load_tile(ca, t + 2);
+          sweep(cb, t + 1);
+          checkpoint(t + 2);
+        }
+      }
+      if constexpr (MODE == PG_MODE_KNN) {
+        while (qn > 0) flush_batch();
+        if (!failed || resweep) break;
+        // phase 1: the rows that lost their cap see tiles [0, tredo) again; the others are frozen
+        if (lane < RB + 8) bndw[lane] = ((failed >> lane) & 1) ? 0u - ((thrv >> 24) + 1u) : 0u;
+        failed |= 0x80000000u;
+        tend = tredo;
+        win_tiles = 0; win_trig = 0; direct_left = 0;
+      } else {
+        break;
       }
     }
 
@@ -438,6 +509,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_nsq_kernel(const NsqParams p
     __builtin_amdgcn_wave_barrier();
   }
 }
+
+#undef resweep
 
 // ---------------------------------------------------------------------------------------
 // Dense (M,N) distance matrix: hamming() operator parity (prograph/distance/hamming.py:34).

@@ -399,6 +399,46 @@ def test_lower_bound_filter_modes_agree(nat, monkeypatch, mode):
     assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
 
 
+@pytest.mark.parametrize("guess", ["0", "3", "8", "40"])
+def test_knn_optimistic_cap_is_exact(nat, monkeypatch, guess):
+    """PG_KNN_GUESS (the optimistic stage-1 cap of the kNN engine) never changes results: rows that
+    settle below the cap, rows that lose it at the first checkpoint (no near column: random rows),
+    rows that lose it at the second (near columns, but fewer than k + 1 below the cap), the second
+    sweep of the early tiles with ties decided by full keys and duplicates skipped, continuation
+    rounds (k > 63) and row windows.  0 switches the mechanism off."""
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    monkeypatch.setenv("PG_KNN_GUESS", guess)
+    rng = np.random.RandomState(11)
+    clustered = synth.clustered_tokens(9000, 64, seed=3, members=128)
+    small = synth.clustered_tokens(3000, 64, seed=4, members=12)          # 11 mates < k: bound far above the cap
+    small[small > 0] = (small[small > 0] % 20) + 1
+    loose = rng.randint(1, 21, size=(3000, 64)).astype(np.uint8)           # no structure at all
+    tok = np.concatenate([clustered, small, loose])[rng.permutation(15000)]
+    tok[100] = tok[7000]; tok[101] = tok[7000]; tok[14000] = tok[7000]     # duplicates, early and late columns
+    tok[200, :60] = tok[9000, :60]                                        # a near pair far apart in column order
+    for bits in BITS:
+        p = _planes(nat, tok, bits)
+        for k in (1, 16, 63, 70):
+            idx, d = nat.knn_graph(p, p, k)
+            ridx, rd = C.knn(tok, k)
+            assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd), (bits, k, guess)
+        idx, d = nat.knn_graph(p, p, 16, row0=5000, nrows=4097)
+        ridx, rd = C.knn(tok, 16, row0=5000, nrows=4097)
+        assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
+    # longer records (one column per lane) and a short sweep (checkpoints at tile 1)
+    tok = synth.clustered_tokens(4000, 128, seed=8, members=40)
+    p = _planes(nat, tok, 5)
+    idx, d = nat.knn_graph(p, p, 16)
+    ridx, rd = C.knn(tok, 16)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
+    tok = synth.clustered_tokens(300, 32, seed=9, members=30)
+    p = _planes(nat, tok, 5)
+    idx, d = nat.knn_graph(p, p, 8)
+    ridx, rd = C.knn(tok, 8)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
+
+
 def test_randomised_shapes_against_c_oracle(nat):
     """Seeded sweep over shapes that hit every template instance (G = 1..4 groups, 5 / 8 bit planes,
     C = 4 / 2 / 1 columns per lane), odd N, odd L, tiny and skewed alphabets, every comparator,
