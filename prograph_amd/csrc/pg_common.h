@@ -125,6 +125,21 @@ struct HammingMetric {
   // the same bound in two steps, so that the engine can issue the 2-cycle logic ops of a whole row
   // group as one run and the 4-cycle popcounts as another (mixed streams run everything at the
   // 4-cycle rate: tools/ubench/valu_s1.hip)
+  // Filter signature of a sequence: the XOR of the plane-0 words of all its groups (record dwords
+  // 0..G-1).  A differing signature bit means that an odd number of the tokens folded onto it
+  // differ in bit 0, so popcount(sig_a ^ sig_b) is a lower bound of the Hamming distance that looks
+  // at EVERY position (the plane-0 word of group 0 alone only sees the first 32): near pairs are
+  // rejected more often, unrelated pairs as before (each bit still differs with probability 1/2).
+  // The engine folds a column once per tile and a row once per pass.
+  static constexpr bool kSigFold = G > 1;                 // one group: the plane-0 word is the signature
+  static __device__ __forceinline__ u32 fold(const uint4 (&rec)[Q]) {
+    u32 w[4 * Q];
+    unpack<Q>(rec, w);
+    u32 s = w[0];
+#pragma unroll
+    for (int g = 1; g < G; ++g) s ^= w[g];
+    return s;
+  }
   static __device__ __forceinline__ u32 lb_prep(const uint4 &r0, const uint4 &c0) { return r0.x ^ c0.x; }
   static __device__ __forceinline__ u32 lb_finish(u32 x, const uint4 &r0, const uint4 &c0, u32 seed) {
     constexpr int GL = G < PG_LB_GROUPS ? G : PG_LB_GROUPS;
@@ -146,6 +161,8 @@ struct BagMetric {
   // stage-1 bound of the engine: the SAD over the first 16 symbols (chunk 0) already exceeds
   // 2*band for almost every unrelated pair: 4 v_sad_u8 instead of 9 + v_max
   static constexpr bool kHasLB = true;
+  static constexpr bool kSigFold = false;
+  static __device__ __forceinline__ u32 fold(const uint4 (&)[Q]) { return 0u; }
   static __device__ __forceinline__ u32 lb_prep(const uint4 &, const uint4 &) { return 0u; }
   static __device__ __forceinline__ u32 lb_finish(u32, const uint4 &r0, const uint4 &c0, u32 seed) {
     return lower_bound(r0, c0, seed);

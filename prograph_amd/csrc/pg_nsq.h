@@ -25,9 +25,10 @@
 #include <type_traits>
 
 template <class M, int C, int MODE>
-// kNN instances with two columns per lane are held at 4 (records of <= 3 chunks) / 3 waves per SIMD
+// kNN instances are held at the occupancy they had before the optimistic-start state was added:
+// two columns per lane 4 (records of <= 3 chunks) / 3 waves per SIMD, one column per lane 3 (<= 5 chunks)
 __global__ __launch_bounds__(PG_WG_THREADS)
-__attribute__((amdgpu_waves_per_eu((MODE == PG_MODE_KNN && C == 2) ? (M::Q <= 3 ? 4 : 3) : 1, 8))) void pg_nsq_kernel(const NsqParams p) {
+__attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 4 : 3) : (M::Q <= 5 ? 3 : 1)) : 1, 8))) void pg_nsq_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
   constexpr int RB = MODE == PG_MODE_KNN ? PG_RB_KNN : PG_RB;   // rows per pass
   constexpr int LROWS = MODE == PG_MODE_KNN ? RB : 1;
@@ -36,6 +37,7 @@ __attribute__((amdgpu_waves_per_eu((MODE == PG_MODE_KNN && C == 2) ? (M::Q <= 3 
   __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
   __shared__ uint4 bndbuf[PG_WG_WAVES][RB / 4 + 2];        // kNN: per row minus the current (k+1)-th distance
   __shared__ u32 capbuf[PG_WG_WAVES][MODE == PG_MODE_KNN ? RB + 4 : 1];   // kNN: per row cap on the published bound
+  __shared__ uint4 sigbuf[PG_WG_WAVES][M::kSigFold ? RB / 4 + 2 : 1];   // filter signatures of the pass's rows, 4 per read
   __shared__ u32 cqbuf[PG_WG_WAVES][QCAP];                 // deferred candidates: kNN row << 24 | column, eps {row, column} pairs
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -86,6 +88,17 @@ __attribute__((amdgpu_waves_per_eu((MODE == PG_MODE_KNN && C == 2) ? (M::Q <= 3 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (M::kSigFold) {
+      if (lane < RB + 8) {                                  // rows >= nr are zero records: signature 0
+        uint4 rec[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) rec[q] = lane < RB + 4 ? rowbuf[wv][lane][q] : make_uint4(0, 0, 0, 0);
+        reinterpret_cast<u32 *>(&sigbuf[wv][0])[lane] = M::fold(rec);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 
     // Per-row state lives in ONE VGPR each, indexed by lane = row-in-pass and touched with
     // v_readlane / a lane-select (row index is wave uniform):
@@ -308,34 +321,63 @@ __attribute__((amdgpu_waves_per_eu((MODE == PG_MODE_KNN && C == 2) ? (M::Q <= 3 
       // running LDS pointers (one v_add each per group instead of one address per read)
       const uint4 *rp = rows;
       const uint4 *bp = bnds;
-      // Two register sets (chunk 0 of four rows + their bounds) swap roles: while one group is
-      // evaluated the next one's LDS reads are in flight.
-      uint4 r4a[4], r4b[4];
+      // Two register sets (the four rows' stage-1 operands + their bounds) swap roles: while one
+      // group is evaluated the next one's LDS reads are in flight.  Stage-1 operand of a row: its
+      // filter signature (Hamming: four rows in one ds_read_b128) or chunk 0 of its record.
+      struct RowOp {
+        uint4 v[M::kSigFold ? 1 : 4];
+      };
+      const uint4 *sp = &sigbuf[wv][0] + opaque_zero();
+      auto load_rowop = [&](RowOp &o, int ahead) {
+        if constexpr (M::kSigFold) {
+          o.v[0] = sp[ahead];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) o.v[u] = rp[(4 * ahead + u) * Q];
+        }
+      };
+      u32 csig[C];                                          // the tile's column signatures
+      if constexpr (M::kSigFold) {
+#pragma unroll
+        for (int b = 0; b < C; ++b) csig[b] = M::fold(c[b]);
+      }
+      RowOp r4a, r4b;
       // bounds travel NEGATED: they seed the popcount accumulator, so stage 1 yields lb - bound and
       // "lb < bound" is the sign bit; the signs of a whole group are OR-ed with 2-cycle logic ops
       // and examined with ONE v_cmp (v_min / v_cmp / v_bcnt are 4-cycle instructions on gfx950,
       // xor / or / bitop3 take 2: tools/ubench/valu_ops.hip)
       const u32 nhi = opaque_vgpr(0u - p.hi1);   // a VGPR, or hipcc splits the seeded popcount into bcnt + sub
       uint4 bnda = make_uint4(nhi, nhi, nhi, nhi), bndb = bnda;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) r4a[u] = rp[u * Q];
+      load_rowop(r4a, 0);
       if constexpr (MODE == PG_MODE_KNN) bnda = bp[0];
-      auto group = [&](const uint4 (&r4)[4], const uint4 &bnd, uint4 (&r4n)[4], uint4 &bndn, int rr) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) r4n[u] = rp[(4 + u) * Q];
+      auto group = [&](const RowOp &r4, const uint4 &bnd, RowOp &r4n, uint4 &bndn, int rr) {
+        load_rowop(r4n, 1);
         if constexpr (MODE == PG_MODE_KNN) bndn = bp[1];
         __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads ahead of the arithmetic
         const u32 nb[4] = {bnd.x, bnd.y, bnd.z, bnd.w};
         u32 t[4][C], o[4];
+        if constexpr (M::kSigFold) {
+          const u32 rs[4] = {r4.v[0].x, r4.v[0].y, r4.v[0].z, r4.v[0].w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int b = 0; b < C; ++b) t[u][b] = M::lb_prep(r4[u], c[b][0]);
-        __builtin_amdgcn_sched_barrier(0);       // run of 2-cycle ops | run of 4-cycle ops
+            for (int b = 0; b < C; ++b) t[u][b] = rs[u] ^ csig[b];
+          __builtin_amdgcn_sched_barrier(0);     // run of 2-cycle ops | run of 4-cycle ops
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int b = 0; b < C; ++b) t[u][b] = M::lb_finish(t[u][b], r4[u], c[b][0], nb[u]);
+            for (int b = 0; b < C; ++b) t[u][b] = __builtin_popcount(t[u][b]) + nb[u];   // seeded v_bcnt
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int b = 0; b < C; ++b) t[u][b] = M::lb_prep(r4.v[u], c[b][0]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int b = 0; b < C; ++b) t[u][b] = M::lb_finish(t[u][b], r4.v[u], c[b][0], nb[u]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // OR of all 4*C signs with three-input ors (4 instructions for 8 values; every VALU
         // instruction of this mixed stream costs about the same, so fewer is better)
@@ -399,6 +441,7 @@ __attribute__((amdgpu_waves_per_eu((MODE == PG_MODE_KNN && C == 2) ? (M::Q <= 3 
         }
         rp += 4 * Q;
         bp += 1;
+        sp += 1;
       };
       for (int rr = 0; rr < nr; rr += 8) {
         group(r4a, bnda, r4b, bndb, rr);
