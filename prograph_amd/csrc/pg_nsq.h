@@ -4,29 +4,36 @@
 // :756-762 of the reference): distance(X, batch) -> mask/where or sort -> gather.
 //
 // Mapping (CDNA4, wave64):
-//   * one LANE owns C (= 2) COLUMN sequences: their bit-sliced records (pg_common.h) sit in VGPRs,
-//     loaded from the chunk-major layout as fully coalesced global_load_dwordx4 (1 KiB per wave
-//     instruction); the next column tile is prefetched into a second register set while the
+//   * one LANE owns C (1 or 2) COLUMN sequences: their bit-sliced records (pg_common.h) sit in
+//     VGPRs, loaded from the chunk-major layout as fully coalesced global_load_dwordx4 (1 KiB per
+//     wave instruction); the next column tile is prefetched into a second register set while the
 //     current one is being compared;
-//   * one WAVE owns a block of up to RB=16 ROW sequences, staged once per pass into a
-//     wave-private LDS region and read back as broadcast ds_read_b128 (all lanes the same
-//     address): the row operand costs a few LDS cycles per 64*C pairs;
-//   * the wave sweeps ALL column tiles in ascending order for its rows, therefore every row's
-//     matches are produced in ascending column order by exactly one wave: the reference's
-//     `torch.where` order (prograph/prograph.py:736) without any sort, and the canonical
-//     (distance, index) kNN order without a merge;
-//   * per row-step (64*C pairs) the epilogue is C-1 v_min + 1 v_cmp and ONE wave-uniform
-//     branch on the ballot; compaction (mbcnt) and sorted insertion (DPP wave_shr + v_readlane)
-//     only run in the rarely taken slow path.
-// No MFMA: the inner loop is boolean bit-plane logic (xor / bitop3 / popcount), B+1 VALU ops per
-// 32 tokens; the operand matrix is cache resident, see DESIGN.md for the roofline.
+//   * one WAVE owns a pass of up to 32 (eps) / 28 (kNN) ROW sequences, staged once per pass into a
+//     wave-private LDS region and read back as broadcast LDS reads (all lanes the same address);
+//   * the wave sweeps ALL column tiles in ascending order for its rows, therefore every row is owned
+//     by exactly one wave: eps matches come out in ascending column order (the reference's
+//     `torch.where` order, prograph/prograph.py:736) without a sort, kNN lists are kept sorted by
+//     (distance, column) keys in LDS (64 lanes = 64 list slots, insertion = one DPP shift);
+//   * a row-step (64*C pairs) normally costs only STAGE 1: a lower bound of the distance from 32-bit
+//     filter signatures (v_xor + seeded v_bcnt, sign bit = "may be below the row's bound"), four
+//     rows per group, one v_cmp + one branch per group;
+//   * lanes that pass stage 1 are QUEUED (row, column) in LDS and evaluated exactly 64 at a time,
+//     one candidate per lane, with gathered records; sub-tiles where many lanes pass, and whole
+//     tiles while most row-steps trigger (dense data), are evaluated in place instead ("direct
+//     form": all exact distances of the sub-tile, the column records are already in registers);
+//   * kNN rows start with an optimistic cap on their stage-1 bound and, if they lose it at a
+//     checkpoint, see the early tiles a second time at the end of the pass (exactness argument at
+//     the definition of G0 below).
+// No MFMA: the inner loop is boolean bit-plane logic (xor / bitop3 / popcount); the operand matrix
+// is cache resident and the kernel is VALU-instruction bound, see DESIGN.md §4.1 for the roofline.
 #pragma once
 #include "pg_common.h"
 #include <type_traits>
 
+// kNN instances are held at the occupancy they had before the optimistic-start state was added
+// (the extra scalar state spills a few SGPRs outside the loops instead of costing a wave): two
+// columns per lane 4 (records of <= 3 chunks) / 3 waves per SIMD, one column per lane 3 (<= 5 chunks)
 template <class M, int C, int MODE>
-// kNN instances are held at the occupancy they had before the optimistic-start state was added:
-// two columns per lane 4 (records of <= 3 chunks) / 3 waves per SIMD, one column per lane 3 (<= 5 chunks)
 __global__ __launch_bounds__(PG_WG_THREADS)
 __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 4 : 3) : (M::Q <= 5 ? 3 : 1)) : 1, 8))) void pg_nsq_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
@@ -308,13 +315,12 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
       }
     };
 
-    // Filtered form: rows are taken FOUR at a time.  Stage 1 of the four rows (lower bounds from
-    // chunk 0, min over the C sub-tiles, compare with the row's bound) is straight-line code with
-    // four independent dependency chains and no branch; the four wave masks are then examined
-    // with scalar branches, and only rows whose mask is non-zero enter stage 2.  This keeps the
-    // VALU busy at 3 waves per SIMD: the serial tail (ballot -> branch) is paid once per 4 rows.
-    // kNN bounds come from LDS (one broadcast ds_read_b128 = the four rows' current (k+1)-th
-    // distances, written by the slow path), eps uses the constant hi+1.
+    // Filtered form: rows are taken FOUR at a time.  Stage 1 of the four rows (signature lower
+    // bounds seeded with minus the row's bound, see below) is straight-line code with no branch;
+    // the OR of all signs is examined with one compare + one scalar branch per group, and only
+    // then the rows / sub-tiles that have passing lanes are looked at.  kNN bounds come from LDS
+    // (one broadcast ds_read_b128 = the four rows' current bounds, written by the slow paths), eps
+    // uses the constant hi+1.  Returns the number of triggered row-steps (for the window heuristic).
     auto sweep_filtered = [&](const uint4 (&c)[C][Q], int t) -> int {
       const u32 col0 = (u32)(t * (64 * C)) + lane;
       int trig = 0;
