@@ -1,0 +1,49 @@
+"""Randomised stress of the all-pairs engine against the C oracle (not part of the test-suite: minutes).
+usage: tools/stress.py [iterations] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from prograph_amd import _native as nat
+from oracle import c_oracle as C
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+for it in range(iters):
+    N = int(rng.choice([300, 1000, 2500, 6000, 12000, 20000]))
+    amax = int(rng.choice([2, 4, 20, 31, 200]))
+    L = int(rng.randint(4, 255 if amax <= 31 else 129))
+    ncl = max(1, N // int(rng.choice([8, 24, 100, 400, 3000])))
+    base = rng.randint(0, amax + 1, size=(ncl, L))
+    tok = base[rng.randint(0, ncl, size=N)].copy()
+    nm = rng.randint(0, int(rng.choice([2, 4, 12])), size=N)
+    for t in range(int(nm.max())):
+        act = np.nonzero(nm > t)[0]
+        tok[act, rng.randint(0, L, size=len(act))] = rng.randint(0, amax + 1, size=len(act))
+    nloose = int(N * rng.choice([0, 0, 0.1, 0.5]))
+    if nloose:
+        tok[rng.choice(N, nloose, replace=False)] = rng.randint(0, amax + 1, size=(nloose, L))
+    tok = tok[rng.permutation(N)].astype(np.uint8) if rng.rand() < 0.5 else tok.astype(np.uint8)
+    bits = 5 if (amax <= 31 and (L > 128 or rng.rand() < 0.7)) else 8
+    os.environ["PG_KNN_GUESS"] = str(rng.choice([0, 2, 5, 8, 8, 8, 20]))
+    os.environ["PG_LB_FILTER"] = str(rng.choice([0, 1, 1, 1, 2]))
+    p = nat.pack(torch.from_numpy(tok), bits=bits)
+    k = int(rng.choice([1, 5, 16, 40, 63, 90]))
+    lo = int(rng.randint(0, N // 2)); nr = int(rng.randint(1, N - lo + 1)) if rng.rand() < 0.5 else None
+    if nr is None: lo = 0
+    idx, d = nat.knn_graph(p, p, k, row0=lo, nrows=nr)
+    ridx, rd = C.knn(tok, k, row0=lo, nrows=(N - lo if nr is None else nr))
+    ok1 = np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
+    eps = int(rng.choice([1, 2, 3, 6, L // 2]))
+    cmp = int(rng.choice([nat.CMP_LE, nat.CMP_LE, nat.CMP_LT, nat.CMP_EQ, nat.CMP_GE, nat.CMP_GT])) if N <= 2500 else nat.CMP_LE
+    cap = int(rng.choice([4, 64, 512]))
+    ip, ix, w = nat.eps_graph(p, p, cmp, eps, row0=lo, nrows=nr, cap=cap)
+    rip, rix, rw = C.eps_csr(tok, cmp, eps, row0=lo, nrows=(N - lo if nr is None else nr))
+    ok2 = np.array_equal(ip.cpu().numpy(), rip) and np.array_equal(ix.cpu().numpy(), rix) and np.array_equal(w.cpu().numpy(), rw)
+    if not (ok1 and ok2):
+        print(f"MISMATCH it={it} N={N} L={L} amax={amax} bits={bits} k={k} eps={eps} cmp={cmp} cap={cap} row0={lo} nrows={nr} "
+              f"guess={os.environ['PG_KNN_GUESS']} filter={os.environ['PG_LB_FILTER']} knn_ok={ok1} eps_ok={ok2}", flush=True)
+        sys.exit(1)
+    if it % 20 == 0:
+        print(f"it {it} ok ({time.time() - t0:.0f}s) N={N} L={L} bits={bits} k={k}", flush=True)
+print(f"all {iters} iterations ok in {time.time() - t0:.0f}s")
