@@ -119,6 +119,24 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
                  int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts, void *stream);
 
 /*
+ * Square self-graph variant of pg_eps_slots / pg_eps_compact: rows [0,n) against the same n sequences.
+ * Hamming and the five comparators are symmetric, so every unordered pair is evaluated ONCE (the
+ * reference evaluates both orders, prograph/prograph.py:731-739): a match (i, j), i < j, is written to
+ * the front of row i's slot in column order and to the back of row j's slot in arrival order
+ * (counts_lo[j] is an atomic counter, zeroed by the call).  The total per row is
+ * counts_up[i] + counts_lo[i]: the caller adds them, scans (pg_exclusive_scan) and calls
+ * pg_eps_compact_sym, which emits each CSR row in ascending column order (rows that overflow `cap`,
+ * or hold more than 512 entries from below, are recomputed exactly as in pg_eps_compact).  n < 2^27.
+ * The result is identical to pg_eps_slots + pg_eps_compact on the same input.
+ */
+int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bits, int cmp, double eps, int cap,
+                     int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts_up, uint32_t *counts_lo, void *stream);
+int pg_eps_compact_sym(const void *planes, int64_t npad, int64_t n, int l, int bits, int cmp, double eps, int cap,
+                       const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts_up,
+                       const uint32_t *counts_lo, const int64_t *indptr, int32_t *indices, uint8_t *weights,
+                       void *stream);
+
+/*
  * pg_exclusive_scan — indptr[0..n] = exclusive prefix sum of counts[0..n) (int64).
  * Replaces the per-row split of `prod_neighbours` (prograph/prograph.py:646-654).
  * `scratch` must hold pg_scan_scratch_bytes(n) bytes.

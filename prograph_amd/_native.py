@@ -27,7 +27,7 @@ MAX_L, MAX_L_5BIT, MAX_K, MAX_K_ROUNDS, MAX_N_KNN, LEV_MAX_BAND = 128, 255, 63, 
 SYMBOLS = [
     "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_pack_planes",
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
-    "pg_eps_compact", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
+    "pg_eps_compact", "pg_eps_slots_sym", "pg_eps_compact_sym", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
     "pg_lev_profile", "pg_lev_candidates", "pg_lev_knn", "pg_csr_row_stats",
 ]
 
@@ -80,6 +80,9 @@ def _load():
         lib.pg_eps_slots.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
                                      _vp, _vp, _vp, _vp]
         lib.pg_exclusive_scan.argtypes = [_vp, _i64, _vp, _vp, _vp]
+        lib.pg_eps_slots_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]
+        lib.pg_eps_compact_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _vp, _vp]
         lib.pg_eps_compact.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_knn_hamming.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
@@ -247,6 +250,23 @@ def eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
     counts = torch.empty(nrows, dtype=torch.int32, device=dev)
     indptr = torch.empty(nrows + 1, dtype=torch.int64, device=dev)
     scratch = torch.empty(int(L.pg_scan_scratch_bytes(nrows)), dtype=torch.uint8, device=dev)
+    sym = os.environ.get("PG_EPS_SYM", "auto")               # 0 = never, 1 = whenever possible, auto = from 32k rows
+    if (rp is cp and row0 == 0 and nrows == rp.n and rp.n < (1 << 27) and cap >= 2 and sym != "0"
+            and (sym == "1" or rp.n >= 32768)):
+        # the whole square graph of one operand: every unordered pair once (pg_eps_slots_sym)
+        counts_lo = torch.empty(nrows, dtype=torch.int32, device=dev)
+        sargs = (_ptr(rp.buf), rp.npad, rp.n, rp.g * 32, bits, cmp, float(eps), cap, _ptr(slot_idx), _ptr(slot_w),
+                 _ptr(counts), _ptr(counts_lo))
+        _check(L.pg_eps_slots_sym(*sargs, _stream()), "pg_eps_slots_sym")
+        total = counts + counts_lo
+        _check(L.pg_exclusive_scan(_ptr(total), nrows, _ptr(indptr), _ptr(scratch), _stream()), "pg_exclusive_scan")
+        nnz = int(indptr[-1].item())
+        indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+        weights = torch.empty(max(nnz, 1), dtype=torch.uint8, device=dev)[:nnz]
+        if nnz:
+            _check(L.pg_eps_compact_sym(*sargs, _ptr(indptr), _ptr(indices), _ptr(weights), _stream()),
+                   "pg_eps_compact_sym")
+        return indptr, indices, weights
     args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, bits, cmp, float(eps), cap)
     _check(L.pg_eps_slots(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _stream()), "pg_eps_slots")
     _check(L.pg_exclusive_scan(_ptr(counts), nrows, _ptr(indptr), _ptr(scratch), _stream()), "pg_exclusive_scan")

@@ -315,8 +315,8 @@ static const occ_fn kNsqOcc[8] = {pg_occ_nsq_g1, pg_occ_nsq_g2, pg_occ_nsq_g3, p
                                   pg_occ_nsq_g5, pg_occ_nsq_g6, pg_occ_nsq_g7, pg_occ_nsq_g8};
 // resident waves per SIMD (= workgroups per CU) of an engine instance, asked once from the runtime
 static int nsq_occupancy(int groups, int mode, int bits) {
-  static int cache[8][2][2];
-  int &c = cache[groups - 1][mode == PG_MODE_KNN][bits == 8];
+  static int cache[8][3][2];
+  int &c = cache[groups - 1][mode][bits == 8];
   if (c == 0) {
     const int n = kNsqOcc[groups - 1](mode, bits);
     c = n < 1 ? 4 : (n > 8 ? 8 : n);
@@ -465,6 +465,56 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
   int grid = 0;
   if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS, bits), 16.0 * pg_nchunks(l, bits))) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(eps)");
+}
+
+// Square self-graph, every unordered pair evaluated once (Hamming and the comparators are symmetric):
+// the engine sweeps only columns above the row, a match (i, j) goes to the front of row i's slot
+// in column order and to the back of row j's slot through an atomic counter.
+int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bits, int cmp, double eps, int cap,
+                     int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts_up, uint32_t *counts_lo, void *stream) {
+  NsqParams p;
+  if (int rc = fill_nsq(&p, planes, npad, 0, n, planes, npad, n, l, bits)) return rc;
+  if (!slot_idx || !slot_w || !counts_up || !counts_lo || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
+    return fail(PG_E_BADARG, "pg_eps_slots_sym: bad argument");
+  if (n >= (1ll << 27)) return fail(PG_E_TOOMANY, "pg_eps_slots_sym: n must be below 2^27");
+  eps_interval(cmp, eps, &p.lo, &p.span);
+  p.hi1 = (p.lo > 0xFFFFFF00u - 1u) ? 0u : p.lo + p.span + 1u;
+  p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts_up; p.countsLo = counts_lo;
+  hipError_t e = hipMemsetAsync(counts_lo, 0, (size_t)n * sizeof(uint32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(e, "hipMemsetAsync");
+  int grid = 0;
+  // Rows near the top sweep almost everything, rows near the bottom almost nothing; workgroups are
+  // dispatched in row order, i.e. longest first, which balances by itself once there are a few
+  // waves per resident slot.  Measured (tools/eps_sym_probe.py): 8 rows per wave at N = 50k, 16 at
+  // N = 200k (more rows: too few waves to balance; fewer: the per-wave column stream shows).
+  if (!getenv("PG_ROWS_PER_WAVE") && !getenv("PG_WAVES_PER_CU")) {
+    long long r = (n / 12500 + 3) / 4 * 4;
+    r = r < 8 ? 8 : (r > 16 ? 16 : r);
+    p.rowsPerWave = (int)r; p.rowsPerPass = (int)r;
+    grid = (int)(((n + r - 1) / r + PG_WG_WAVES - 1) / PG_WG_WAVES);
+  } else if (int rc = plan_rows(n, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS_SYM, bits), 16.0 * pg_nchunks(l, bits), 16)) {
+    return rc;
+  }
+  return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_EPS_SYM, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(eps sym)");
+}
+
+int pg_eps_compact_sym(const void *planes, int64_t npad, int64_t n, int l, int bits, int cmp, double eps, int cap,
+                       const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts_up,
+                       const uint32_t *counts_lo, const int64_t *indptr, int32_t *indices, uint8_t *weights,
+                       void *stream) {
+  CompactParams c;
+  if (int rc = fill_nsq(&c.e, planes, npad, 0, n, planes, npad, n, l, bits)) return rc;
+  if (!slot_idx || !slot_w || !counts_up || !counts_lo || !indptr || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
+    return fail(PG_E_BADARG, "pg_eps_compact_sym: bad argument");
+  eps_interval(cmp, eps, &c.e.lo, &c.e.span);
+  c.e.hi1 = c.e.lo + c.e.span + 1u;
+  c.e.cap = (u32)cap;
+  c.e.slotIdx = const_cast<int *>(slot_idx);
+  c.e.slotW = const_cast<unsigned char *>(slot_w);
+  c.e.counts = const_cast<u32 *>(counts_up);
+  c.e.countsLo = const_cast<u32 *>(counts_lo);
+  c.indptr = (const long long *)indptr; c.indices = indices; c.weights = weights;
+  return launched(kCompact[pg_ngroups(l) - 1](bits, c, (hipStream_t)stream), "pg_compact_kernel(sym)");
 }
 
 int64_t pg_scan_scratch_bytes(int64_t n) {

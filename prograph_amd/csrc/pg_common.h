@@ -11,12 +11,13 @@ typedef unsigned long long u64;
 #define PG_WG_THREADS (PG_WAVE * PG_WG_WAVES)
 #define PG_RB 32    // rows per wave pass of the all-pairs engine (<= 64: per-row state is lane indexed)
 #define PG_RB_KNN 28 // kNN passes: 28 rows, so that lists + candidate queue keep 4 workgroups per CU in LDS
+#define PG_SORT_MAX 512 // symmetric eps: a row's back part (entries from lower rows) up to this size is rank-sorted in LDS
 #define PG_QCAP 128  // kNN: entries of the per-wave candidate queue (flushed in batches of 64)
 #define PG_QCAP_EPS 576 // eps: every passing lane is queued (order!), a group can add 4 rows x 2 x 64
 #define PG_PUSH_MAX 8 // kNN: a triggered sub-tile with more passing lanes than this is evaluated in place
 #define PG_RBD 64   // rows per workgroup of the dense kernel
 
-enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1 };
+enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1, PG_MODE_EPS_SYM = 2 };   // EPS_SYM: square self-graph, upper triangle only
 
 // ---------------------------------------------------------------------------------------
 // Mismatch counting on the BIT-SLICED layout.
@@ -210,6 +211,7 @@ struct NsqParams {
   int *slotIdx;
   unsigned char *slotW;
   u32 *counts;
+  u32 *countsLo;  // EPS_SYM: per row, matches found from the other side (column < row), filled with atomics
   // knn: lanes [knnFirst, knnFirst + k) of the sorted 64-key list are written; keys <= floorKeys[row]
   // are ignored (continuation rounds for k > 63); lastKeys[row] receives the last written key
   int k, knnFirst;

@@ -37,6 +37,8 @@ template <class M, int C, int MODE>
 __global__ __launch_bounds__(PG_WG_THREADS)
 __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 4 : 3) : (M::Q <= 5 ? 3 : 1)) : 1, 8))) void pg_nsq_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
+  constexpr bool kEps = MODE != PG_MODE_KNN;              // eps slots, rectangular or symmetric
+  constexpr bool kSym = MODE == PG_MODE_EPS_SYM;          // every unordered pair once: columns above the row only
   constexpr int RB = MODE == PG_MODE_KNN ? PG_RB_KNN : PG_RB;   // rows per pass
   constexpr int LROWS = MODE == PG_MODE_KNN ? RB : 1;
   constexpr int QCAP = MODE == PG_MODE_KNN ? PG_QCAP : (M::kHasLB ? PG_QCAP_EPS : 1);
@@ -60,7 +62,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
   u32 *bndw = reinterpret_cast<u32 *>(&bndbuf[wv][0]);
   // eps: the bias -lo seeds the popcount accumulator (v_bcnt's addend) from an opaque VGPR, so
   // hipcc cannot re-associate it into an extra v_sub per pair
-  const u32 bias = MODE == PG_MODE_EPS ? opaque_vgpr(0u - p.lo) : 0u;
+  const u32 bias = kEps ? opaque_vgpr(0u - p.lo) : 0u;
 
   for (long long pr0 = wr0; pr0 < wr1; pr0 += p.rowsPerPass) {
     const long long left = wr1 - pr0;
@@ -144,9 +146,26 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
         bndw[row] = 0u - (b < cp ? b : cp);
       }
     };
+    // EPS_SYM: a match (row, col), col > row, also belongs to row `col`.  That row is owned by another
+    // wave, so its entry goes to the BACK of its slot (position from an atomic counter, any order;
+    // pg_compact_sym_kernel sorts that part) while the owner fills the front in column order.  Front
+    // and back can only collide when the row overflows its slot, and then it is recomputed anyway.
+    auto emit_lower = [&](bool on, u32 rowg, u32 col, u32 w) {
+      if constexpr (kSym) {
+        if (on) {
+          const u32 pos = atomicAdd(&p.countsLo[col], 1u);
+          if (pos < p.cap) {
+            const long long o = (long long)col * p.cap + (p.cap - 1u - pos);
+            p.slotIdx[o] = (int)rowg;
+            p.slotW[o] = (unsigned char)w;
+          }
+        }
+      }
+    };
     auto epilogue = [&](u32 d, u32 col, int rr) {
-      if constexpr (MODE == PG_MODE_EPS) {
-        const bool h2 = (d <= p.span) && (col < ncols);
+      if constexpr (kEps) {
+        bool h2 = (d <= p.span) && (col < ncols);
+        if constexpr (kSym) h2 = h2 && col > (u32)(pr0 + rr);   // the pair's other half comes from emit_lower
         const u64 m2 = __builtin_amdgcn_ballot_w64(h2);
         if (m2) {
           const u32 cnt = __builtin_amdgcn_readlane(cntv, rr);
@@ -157,6 +176,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
             p.slotW[o] = (unsigned char)(d + p.lo);
           }
           cntv = (lane == rr) ? cnt + (u32)__popcll(m2) : cntv;
+          emit_lower(h2, (u32)(pr0 + rr), col, d + p.lo);
         }
       } else {
         u32 thr = __builtin_amdgcn_readlane(thrv, rr);
@@ -242,9 +262,9 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
     // place: slot positions are handed out in queue order, which is ascending column order per
     // row), the queue is drained before a direct-form tile and at the end of the pass.  Needs the
     // column index in 27 bits; wider problems keep the in-place path.
-    const bool deferEps = MODE == PG_MODE_EPS && M::kHasLB && p.ncols < (1ll << 27);
+    const bool deferEps = kEps && M::kHasLB && p.ncols < (1ll << 27);
     auto flush_eps = [&]() {
-      if constexpr (MODE == PG_MODE_EPS && M::kHasLB) {
+      if constexpr (kEps && M::kHasLB) {
         const int nbat = qn < 64 ? qn : 64;
         const u32 e = cqbuf[wv][lane];
         const u32 col = e & 0x07FFFFFFu;
@@ -259,7 +279,9 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
           for (int q = 0; q < Q; ++q) rw[q] = rowbuf[wv][erow][q];
           d = M::dist(rw, cr, bias);
         }
-        const bool match = act && d <= p.span;
+        bool match = act && d <= p.span;
+        if constexpr (kSym) match = match && col > (u32)pr0 + erow;
+        emit_lower(match, (u32)pr0 + erow, col, d + p.lo);
         u64 m = __builtin_amdgcn_ballot_w64(match);
         while (m) {                                          // one turn per row present in the batch
           const u32 row = __builtin_amdgcn_readlane(erow, __builtin_ctzll(m));
@@ -294,7 +316,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
       u32 dmin = d[0];
 #pragma unroll
       for (int b = 1; b < C; ++b) dmin = dmin < d[b] ? dmin : d[b];
-      const u32 bound = MODE == PG_MODE_EPS ? p.span + 1u : (__builtin_amdgcn_readlane(thrv, rr) >> 24);
+      const u32 bound = kEps ? p.span + 1u : (__builtin_amdgcn_readlane(thrv, rr) >> 24);
       if (__builtin_amdgcn_ballot_w64(dmin < bound)) {
 #pragma unroll
         for (int b = 0; b < C; ++b) epilogue(d[b], col0 + b * 64, rr);
@@ -478,7 +500,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
           return;
         }
         if (direct_left > 0) --direct_left;
-        if constexpr (MODE == PG_MODE_EPS) {
+        if constexpr (kEps) {
           while (qn > 0) flush_eps();                       // in-place stores must come after queued ones
         }
       }
@@ -510,9 +532,10 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
       }
     };
     int tend = ntiles;
+    const int tbeg = kSym ? (int)(pr0 / (64 * C)) : 0;      // EPS_SYM: from the tile that holds the pass's first row
     for (;;) {
-      load_tile(ca, 0);
-      for (int t = 0; t < tend; t += 2) {
+      load_tile(ca, tbeg);
+      for (int t = tbeg; t < tend; t += 2) {
         load_tile(cb, t + 1);
         sweep(ca, t);
         checkpoint(t + 1);
@@ -541,7 +564,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
       while (qn > 0) flush_eps();
     }
     // ---- per-row results of this pass ----
-    if constexpr (MODE == PG_MODE_EPS) {
+    if constexpr (kEps) {
       if (lane < nr) p.counts[pr0 + lane] = cntv;
     } else {
       for (int rr = 0; rr < nr; ++rr) {
@@ -605,16 +628,36 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_dense_kernel(const DensePara
 template <int G, int B>
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_compact_kernel(const CompactParams p) {
   constexpr int Q = Rec<G, B>::Q;
+  __shared__ u32 lcol[PG_WG_WAVES][PG_SORT_MAX];          // symmetric slots: columns of a row's back part
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * PG_WG_WAVES + (threadIdx.x >> 6);
   if (row >= p.e.nrows) return;
-  const u32 cnt = p.e.counts[row];
+  // symmetric slots (pg_eps_slots_sym): `up` entries with column > row at the front of the slot, in
+  // column order; `lo` entries with column < row at the back, in arrival order -> rank-sorted here
+  const u32 up = p.e.counts[row];
+  const u32 lo = p.e.countsLo ? p.e.countsLo[row] : 0u;
+  const u32 cnt = up + lo;
   const long long dst = p.indptr[row];
-  if (cnt <= p.e.cap) {
+  if (cnt <= p.e.cap && lo <= (u32)PG_SORT_MAX) {
     const long long src = row * (long long)p.e.cap;
-    for (u32 i = lane; i < cnt; i += 64) {
-      p.indices[dst + i] = p.e.slotIdx[src + i];
-      p.weights[dst + i] = p.e.slotW[src + i];
+    if (lo) {
+      // rank sort of the back part through the wave's LDS: rank = entries with a smaller column
+      u32 *lc = &lcol[threadIdx.x >> 6][0];
+      for (u32 i = lane; i < lo; i += 64) lc[i] = (u32)p.e.slotIdx[src + p.e.cap - 1u - i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (u32 i = lane; i < lo; i += 64) {
+        const u32 ecol = lc[i];
+        u32 rank = 0;
+        for (u32 j = 0; j < lo; ++j) rank += lc[j] < ecol ? 1u : 0u;
+        p.indices[dst + rank] = (int)ecol;
+        p.weights[dst + rank] = p.e.slotW[src + p.e.cap - 1u - i];
+      }
+    }
+    for (u32 i = lane; i < up; i += 64) {
+      p.indices[dst + lo + i] = p.e.slotIdx[src + i];
+      p.weights[dst + lo + i] = p.e.slotW[src + i];
     }
     return;
   }

@@ -48,11 +48,14 @@ static int occ_nsq() {
 }
 
 int PG_CAT(pg_occ_nsq_g, PG_G)(int mode, int bits) {
+  if (mode == PG_MODE_EPS_SYM) return bits == 5 ? occ_nsq<5, PG_MODE_EPS_SYM>() : occ_nsq<8, PG_MODE_EPS_SYM>();
   if (mode == PG_MODE_EPS) return bits == 5 ? occ_nsq<5, PG_MODE_EPS>() : occ_nsq<8, PG_MODE_EPS>();
   return bits == 5 ? occ_nsq<5, PG_MODE_KNN>() : occ_nsq<8, PG_MODE_KNN>();
 }
 
 int PG_CAT(pg_launch_nsq_g, PG_G)(int mode, int bits, const NsqParams &p, int grid, hipStream_t s) {
+  if (mode == PG_MODE_EPS_SYM)
+    return bits == 5 ? launch_nsq<5, PG_MODE_EPS_SYM>(p, grid, s) : launch_nsq<8, PG_MODE_EPS_SYM>(p, grid, s);
   if (mode == PG_MODE_EPS) return bits == 5 ? launch_nsq<5, PG_MODE_EPS>(p, grid, s) : launch_nsq<8, PG_MODE_EPS>(p, grid, s);
   return bits == 5 ? launch_nsq<5, PG_MODE_KNN>(p, grid, s) : launch_nsq<8, PG_MODE_KNN>(p, grid, s);
 }

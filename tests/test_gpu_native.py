@@ -399,6 +399,50 @@ def test_lower_bound_filter_modes_agree(nat, monkeypatch, mode):
     assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
 
 
+@pytest.mark.parametrize("sym", ["0", "1"])
+def test_eps_symmetric_path_matches_rectangular(nat, monkeypatch, sym):
+    """pg_eps_slots_sym / pg_eps_compact_sym (every unordered pair once, the transposed half delivered
+    through atomic back-of-slot appends and rank-sorted at compaction) against the goldens and the C
+    oracle: every comparator, slot overflow (cap 4), rows with hundreds of entries from below (LDS
+    rank sort, and beyond 512 the recompute path), dense data, duplicates.  PG_EPS_SYM=0 keeps the
+    rectangular path, 1 forces the symmetric one also on small inputs (auto: from 32k rows)."""
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    monkeypatch.setenv("PG_EPS_SYM", sym)
+    for name in ("synth_n2085_l64", "synth_n515_l20_dups", "ref_synthetic_csv"):
+        g = load_golden(name)
+        for bits in BITS:
+            p = _planes(nat, g["tokens"], bits)
+            for key in g.files:
+                if key.endswith("_indptr") and "sub" not in key and "sim" not in key and "_b5" not in key:
+                    base = key[:-7]
+                    parts = base.split("_")
+                    cmp = {"eq": nat.CMP_EQ, "lt": nat.CMP_LT, "ge": nat.CMP_GE, "gt": nat.CMP_GT}[parts[1]] if len(parts) > 1 else nat.CMP_LE
+                    for cap in (4, 64):
+                        ip, ix, w = _csr_np(nat.eps_graph(p, p, cmp, int(parts[0][3:]), cap=cap))
+                        assert np.array_equal(ip, g[base + "_indptr"]) and np.array_equal(ix, g[base + "_indices"]), (name, base, cap)
+                        assert np.array_equal(w, g[base + "_weights"])
+    # one dense cluster: every row has ~all others within eps (back parts of 100s .. 1000s of entries)
+    tok = synth.clustered_tokens(3000, 64, seed=21, members=3000)
+    p = _planes(nat, tok, 5)
+    for eps, cap in ((2, 256), (4, 1024), (6, 4096), (6, 64)):
+        ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, eps, cap=cap))
+        rip, rix, rw = C.eps_csr(tok, nat.CMP_LE, eps)
+        assert np.array_equal(ip, rip) and np.array_equal(ix, rix) and np.array_equal(w, rw), (eps, cap)
+    # a longer sweep, clusters + loose rows, GE comparator (most pairs match)
+    tok = np.concatenate([synth.clustered_tokens(20000, 40, seed=5, members=50),
+                          np.random.RandomState(3).randint(1, 21, size=(2000, 40)).astype(np.uint8)])
+    p = _planes(nat, tok, 5)
+    ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_LE, 3, cap=64))
+    rip, rix, rw = C.eps_csr(tok, nat.CMP_LE, 3)
+    assert np.array_equal(ip, rip) and np.array_equal(ix, rix) and np.array_equal(w, rw)
+    tok = synth.clustered_tokens(1500, 24, seed=6, members=30)
+    p = _planes(nat, tok, 5)
+    ip, ix, w = _csr_np(nat.eps_graph(p, p, nat.CMP_GE, 20, cap=32))
+    rip, rix, rw = C.eps_csr(tok, nat.CMP_GE, 20)
+    assert np.array_equal(ip, rip) and np.array_equal(ix, rix) and np.array_equal(w, rw)
+
+
 @pytest.mark.parametrize("guess", ["0", "3", "8", "40"])
 def test_knn_optimistic_cap_is_exact(nat, monkeypatch, guess):
     """PG_KNN_GUESS (the optimistic stage-1 cap of the kNN engine) never changes results: rows that

@@ -27,6 +27,7 @@ for it in range(iters):
     bits = 5 if (amax <= 31 and (L > 128 or rng.rand() < 0.7)) else 8
     os.environ["PG_KNN_GUESS"] = str(rng.choice([0, 2, 5, 8, 8, 8, 20]))
     os.environ["PG_LB_FILTER"] = str(rng.choice([0, 1, 1, 1, 2]))
+    os.environ["PG_EPS_SYM"] = str(rng.choice([0, 1]))
     p = nat.pack(torch.from_numpy(tok), bits=bits)
     k = int(rng.choice([1, 5, 16, 40, 63, 90]))
     lo = int(rng.randint(0, N // 2)); nr = int(rng.randint(1, N - lo + 1)) if rng.rand() < 0.5 else None
@@ -42,7 +43,7 @@ for it in range(iters):
     ok2 = np.array_equal(ip.cpu().numpy(), rip) and np.array_equal(ix.cpu().numpy(), rix) and np.array_equal(w.cpu().numpy(), rw)
     if not (ok1 and ok2):
         print(f"MISMATCH it={it} N={N} L={L} amax={amax} bits={bits} k={k} eps={eps} cmp={cmp} cap={cap} row0={lo} nrows={nr} "
-              f"guess={os.environ['PG_KNN_GUESS']} filter={os.environ['PG_LB_FILTER']} knn_ok={ok1} eps_ok={ok2}", flush=True)
+              f"guess={os.environ['PG_KNN_GUESS']} filter={os.environ['PG_LB_FILTER']} sym={os.environ['PG_EPS_SYM']} knn_ok={ok1} eps_ok={ok2}", flush=True)
         sys.exit(1)
     if it % 20 == 0:
         print(f"it {it} ok ({time.time() - t0:.0f}s) N={N} L={L} bits={bits} k={k}", flush=True)
