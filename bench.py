@@ -197,7 +197,28 @@ def main():
         planes = _native.pack(full, bits=5)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        if wl["mode"] == "eps":
+        if wl["mode"] == "eps" and lo == 0 and rows_local == N and os.environ.get("PG_EPS_SYM", "auto") != "0":
+            # the whole square graph on one GPU: the symmetric path (what Prograph.build_graph takes)
+            L_ = _native.lib()
+            counts_lo = torch.empty(rows_local, dtype=torch.int32, device=dev)
+            sargs = (_native._ptr(planes.buf), planes.npad, planes.n, planes.g * 32, planes.bits, _native.CMP_LE,
+                     float(wl["eps"]), cap, _native._ptr(slot_idx), _native._ptr(slot_w), _native._ptr(counts),
+                     _native._ptr(counts_lo))
+            _native._check(L_.pg_eps_slots_sym(*sargs, _native._stream()), "pg_eps_slots_sym")
+            e1.record()
+            total = counts + counts_lo
+            indptr = torch.empty(rows_local + 1, dtype=torch.int64, device=dev)
+            scratch = torch.empty(int(L_.pg_scan_scratch_bytes(rows_local)), dtype=torch.uint8, device=dev)
+            _native._check(L_.pg_exclusive_scan(_native._ptr(total), rows_local, _native._ptr(indptr),
+                                                _native._ptr(scratch), _native._stream()), "scan")
+            nnz = int(indptr[-1].item())
+            indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+            weights = torch.empty(max(nnz, 1), dtype=torch.uint8, device=dev)
+            _native._check(L_.pg_eps_compact_sym(*sargs, _native._ptr(indptr), _native._ptr(indices),
+                                                 _native._ptr(weights), _native._stream()), "compact_sym")
+            result["nnz"] = nnz
+            result["path"] = "symmetric (every unordered pair once)"
+        elif wl["mode"] == "eps":
             _native.eps_slots_only(planes, planes, _native.CMP_LE, wl["eps"], lo, rows_local, cap, slot_idx, slot_w, counts)
             e1.record()
             indptr = torch.empty(rows_local + 1, dtype=torch.int64, device=dev)
@@ -291,6 +312,8 @@ def main():
         }
         if wl["mode"] == "eps":
             line["config"]["nnz"] = result.get("nnz")
+            if result.get("path"):
+                line["config"]["path"] = result["path"]
         if wl["mode"] == "lev":
             line["config"].update({"candidates": result.get("candidates"), "filter_passes": result.get("filter_passes")})
             line["roofline"]["kernel"] = "pg_lev_* (profile + bag filter pg_nsq_kernel<BagMetric> + pg_lev_select_kernel)"
