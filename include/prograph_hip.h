@@ -211,19 +211,26 @@ int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int bits,
  *   pg_lev_candidates  all-pairs necessary-condition filter max(SAD, 2|dlen|) <= 2*band into
  *                      per-row candidate slots (ascending columns, exact counts[] even past cap;
  *                      the caller re-runs with a larger cap when max(counts) > cap)
+ *   pg_lev_candidates_sym  the same for all rows at once with every unordered pair filtered once
+ *                      (slots as in pg_eps_slots_sym: counts_up / counts_lo, the row itself in
+ *                      neither); the caller re-runs with a larger cap when max(up + lo) > cap
  *   pg_lev_knn         exact banded edit distance per candidate (bit-parallel diagonal band) +
  *                      canonical kNN selection; `planes128` = the same tokens packed with
- *                      pg_pack_planes(bits = 5) at width l = 128 (chunk p = bit plane p)
+ *                      pg_pack_planes(bits = 5) at width l = 128 (chunk p = bit plane p);
+ *                      counts_lo = NULL for pg_lev_candidates slots, else the symmetric pair
  */
 int pg_lev_profile(const uint8_t *tokens, int64_t n, int l, int64_t ld, void *profiles,
                    int64_t npad, int32_t *lens, uint32_t *flags, void *stream);
 int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row0, int64_t nrows,
                       int band, int cap, int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts,
                       void *stream);
+int pg_lev_candidates_sym(const void *profiles, int64_t npad, int64_t n, int band, int cap,
+                          int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts_up, uint32_t *counts_lo,
+                          void *stream);
 int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const void *planes128,
                int64_t npad, const int32_t *lens, int64_t row0, int64_t nrows, int band, int k,
-               int cap, const int32_t *slot_idx, const uint32_t *counts, int32_t *idx_out,
-               uint8_t *dist_out, void *stream);
+               int cap, const int32_t *slot_idx, const uint32_t *counts, const uint32_t *counts_lo,
+               int32_t *idx_out, uint8_t *dist_out, void *stream);
 
 /*
  * pg_csr_row_stats — per-row reductions over a CSR graph for the analytics that consume the

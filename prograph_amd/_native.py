@@ -28,7 +28,7 @@ SYMBOLS = [
     "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_pack_planes",
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
     "pg_eps_compact", "pg_eps_slots_sym", "pg_eps_compact_sym", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
-    "pg_lev_profile", "pg_lev_candidates", "pg_lev_knn", "pg_csr_row_stats",
+    "pg_lev_profile", "pg_lev_candidates", "pg_lev_candidates_sym", "pg_lev_knn", "pg_csr_row_stats",
 ]
 
 
@@ -93,8 +93,9 @@ def _load():
         lib.pg_csr_row_stats.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]
         lib.pg_lev_profile.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp]
         lib.pg_lev_candidates.argtypes = [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]
+        lib.pg_lev_candidates_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]
         lib.pg_lev_knn.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
-                                   _vp]
+                                   _vp, _vp]
         for name in SYMBOLS:
             fn = getattr(lib, name)
             if fn.restype is ctypes.c_int and name not in ("pg_version",):
@@ -407,14 +408,22 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
         raise ValueError("levenshtein_knn: at most 128 tokens per sequence")
     planes = pack(tokens, bits=BITS_5, width=128)            # chunk p of a record = bit plane p (128 bits)
     counts = torch.empty(nrows, dtype=torch.int32, device=dev)
+    symenv = os.environ.get("PG_EPS_SYM", "auto")            # the filter is symmetric like the eps graph
+    sym = row0 == 0 and nrows == n and n < (1 << 24) and symenv != "0" and (symenv == "1" or n >= 32768)
+    counts_lo = torch.empty(nrows, dtype=torch.int32, device=dev) if sym else None
     passes = 0
     while True:
         passes += 1
         slot_idx = torch.empty(nrows * cap, dtype=torch.int32, device=dev)
         slot_w = torch.empty(nrows * cap, dtype=torch.uint8, device=dev)
-        _check(L.pg_lev_candidates(_ptr(prof), np_, n, row0, nrows, int(band), int(cap), _ptr(slot_idx), _ptr(slot_w),
-                                   _ptr(counts), _stream()), "pg_lev_candidates")
-        mx = int(counts.max().item())
+        if sym:
+            _check(L.pg_lev_candidates_sym(_ptr(prof), np_, n, int(band), int(cap), _ptr(slot_idx), _ptr(slot_w),
+                                           _ptr(counts), _ptr(counts_lo), _stream()), "pg_lev_candidates_sym")
+            mx = int((counts + counts_lo).max().item())
+        else:
+            _check(L.pg_lev_candidates(_ptr(prof), np_, n, row0, nrows, int(band), int(cap), _ptr(slot_idx),
+                                       _ptr(slot_w), _ptr(counts), _stream()), "pg_lev_candidates")
+            mx = int(counts.max().item())
         if mx <= cap:
             break
         cap = ((mx + 63) // 64) * 64          # some row has more candidates than slots: redo with room
@@ -422,9 +431,10 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
     dist = torch.empty((nrows, k), dtype=torch.uint8, device=dev)
     _check(L.pg_lev_knn(_ptr(tokens), n, l, tokens.stride(0), _ptr(planes.buf), planes.npad, _ptr(lens), row0, nrows,
                         int(band), int(k), int(cap),
-                        _ptr(slot_idx), _ptr(counts), _ptr(idx), _ptr(dist), _stream()), "pg_lev_knn")
+                        _ptr(slot_idx), _ptr(counts), _ptr(counts_lo), _ptr(idx), _ptr(dist), _stream()), "pg_lev_knn")
     if return_stats:
-        return idx, dist, {"candidates": int(counts.to(torch.int64).sum().item()), "cap": cap, "filter_passes": passes}
+        ncand = int(counts.to(torch.int64).sum().item()) + (int(counts_lo.to(torch.int64).sum().item()) if sym else 0)
+        return idx, dist, {"candidates": ncand, "cap": cap, "filter_passes": passes, "symmetric": bool(sym)}
     return idx, dist
 
 

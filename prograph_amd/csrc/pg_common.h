@@ -247,10 +247,11 @@ struct CompactParams {
   int pg_launch_compact_g##G(int bits, const CompactParams &p, hipStream_t s);
 PG_DECL_G(1) PG_DECL_G(2) PG_DECL_G(3) PG_DECL_G(4) PG_DECL_G(5) PG_DECL_G(6) PG_DECL_G(7) PG_DECL_G(8)
 int pg_launch_nsq_bag(const NsqParams &p, int grid, hipStream_t s);   // pg_lev.hip
+int pg_launch_nsq_bag_sym(const NsqParams &p, int grid, hipStream_t s);
 int pg_occ_nsq_bag();
 int pg_launch_lev_profile(const unsigned char *tok, long long n, int l, long long ld, u32 *prof, long long npad,
                           int *lens, u32 *flags, hipStream_t s);
 int pg_launch_lev_select(const unsigned char *tok, long long n, int l, long long ld, const uint4 *planes,
                          long long npad, const int *lens, long long row0,
-                         long long nrows, int band, int k, u32 cap, const int *slotIdx, const u32 *counts,
+                         long long nrows, int band, int k, u32 cap, const int *slotIdx, const u32 *counts, const u32 *countsLo,
                          int *knnIdx, unsigned char *knnDist, hipStream_t s);

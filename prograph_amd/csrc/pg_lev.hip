@@ -30,6 +30,11 @@ int pg_occ_nsq_bag() {
   return n;
 }
 
+int pg_launch_nsq_bag_sym(const NsqParams &p, int grid, hipStream_t s) {
+  pg_nsq_kernel<BagMetric, 2, PG_MODE_EPS_SYM><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+  return (int)hipGetLastError();
+}
+
 int pg_launch_nsq_bag(const NsqParams &p, int grid, hipStream_t s) {
   pg_nsq_kernel<BagMetric, 2, PG_MODE_EPS><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
   return (int)hipGetLastError();
@@ -85,6 +90,7 @@ struct LevParams {
   u32 cap;
   const int *slotIdx;
   const u32 *counts;
+  const u32 *countsLo;   // symmetric candidate slots (pg_lev_candidates_sym): entries found from the other side, or null
   int *knnIdx;
   unsigned char *knnDist;
 };
@@ -128,12 +134,20 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_lev_select_kernel(const LevP
   const uint4 *am = &amask[wv][0][0] + opaque_zero();
 
   u32 lst = 0xFFFFFFFFu, thr = 0xFFFFFFFFu;            // sorted keys across lanes / (k+1)-th key
-  const u32 cnt = p.counts[lr];
+  // symmetric slots: `up` candidates (column > row) at the front, `lo` (column < row) at the back in
+  // arbitrary order, the row itself in neither: it enters here as key (0, row).  Keys are totally
+  // ordered and every insertion compares whole keys, so the order of arrival does not matter.
+  const u32 up = p.counts[lr];
+  const u32 lo = p.countsLo ? p.countsLo[lr] : 0u;
+  if (p.countsLo && lane == 0) lst = (u32)row;
+  const u32 cnt = up + lo;
   const u32 ncand = cnt < p.cap ? cnt : p.cap;         // host guarantees cnt <= cap (re-runs otherwise)
 
   for (u32 c0 = 0; c0 < ncand; c0 += 64) {
     const bool have = c0 + lane < ncand;
-    const int col = have ? p.slotIdx[lr * (long long)p.cap + c0 + lane] : 0;
+    const u32 ci = c0 + lane;
+    const u32 spos = ci < up ? ci : p.cap - 1u - (ci - up);
+    const int col = have ? p.slotIdx[lr * (long long)p.cap + spos] : 0;
     const int lb = have ? p.lens[col] : 0;
     u32 P[5][6];                                        // plane p as dwords [zero, w0, w1, w2, w3, zero]
 #pragma unroll
@@ -242,11 +256,11 @@ int pg_launch_lev_profile(const unsigned char *tok, long long n, int l, long lon
 
 int pg_launch_lev_select(const unsigned char *tok, long long n, int l, long long ld, const uint4 *planes,
                          long long npad, const int *lens, long long row0,
-                         long long nrows, int band, int k, u32 cap, const int *slotIdx, const u32 *counts,
+                         long long nrows, int band, int k, u32 cap, const int *slotIdx, const u32 *counts, const u32 *countsLo,
                          int *knnIdx, unsigned char *knnDist, hipStream_t s) {
   LevParams p;
   p.tok = tok; p.n = n; p.ld = ld; p.l = l; p.planes = planes; p.npad = npad; p.lens = lens; p.row0 = row0; p.nrows = nrows;
-  p.band = band; p.k = k; p.cap = cap; p.slotIdx = slotIdx; p.counts = counts; p.knnIdx = knnIdx; p.knnDist = knnDist;
+  p.band = band; p.k = k; p.cap = cap; p.slotIdx = slotIdx; p.counts = counts; p.countsLo = countsLo; p.knnIdx = knnIdx; p.knnDist = knnDist;
   pg_lev_select_kernel<<<dim3((unsigned)((nrows + PG_WG_WAVES - 1) / PG_WG_WAVES)), dim3(PG_WG_THREADS), 0, s>>>(p);
   return (int)hipGetLastError();
 }

@@ -269,10 +269,12 @@ def test_full_size_properties(nat, cfg):
         assert np.array_equal(kidx[r], order) and np.array_equal(kd[r], d[order])
 
 
-def test_levenshtein_knn_vs_oracle(nat):
+@pytest.mark.parametrize("sym", ["0", "1"])
+def test_levenshtein_knn_vs_oracle(nat, monkeypatch, sym):
     """Build-defined banded Levenshtein kNN (no reference counterpart: parity unpinned) against the
     C oracle's plain banded Wagner–Fischer, incl. empty rows, duplicates, bands < 8 and the
-    candidate-slot overflow re-run."""
+    candidate-slot overflow re-run; with the rectangular and the symmetric candidate filter."""
+    monkeypatch.setenv("PG_EPS_SYM", sym)
     from oracle import c_oracle as C
     from oracle import prograph_oracle as O
     from prograph_amd import synth
