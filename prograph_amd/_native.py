@@ -239,44 +239,57 @@ def eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
     """
     Epsilon-neighbourhood CSR of rows [row0, row0+nrows) of `rp` against all of `cp`.
     Returns device tensors (indptr int64 [nrows+1], indices int32 [nnz], weights uint8 [nnz]).
-    One host sync (reading nnz) sits between the N^2 pass and the compaction.
+    One host sync (reading nnz and the overflow statistics) sits between the N^2 pass and the
+    compaction.  Rows with more matches than `cap` stay exact (the compaction kernel recomputes
+    them), but a recomputed row costs a full sweep by one wave: when more than 2 % of the rows
+    overflow, the N^2 pass is repeated once with a capacity that covers 99.5 % of the rows
+    (bounded by PG_SLOT_BYTES_MAX, default 4 GiB of slots).
     """
     L = lib()
     nrows = rp.n - row0 if nrows is None else int(nrows)
     dev = rp.buf.device
     bits = _bits2(rp, cp)
     cap = int(cap)
-    slot_idx = torch.empty(nrows * cap, dtype=torch.int32, device=dev)
-    slot_w = torch.empty(nrows * cap, dtype=torch.uint8, device=dev)
+    symenv = os.environ.get("PG_EPS_SYM", "auto")            # 0 = never, 1 = whenever possible, auto = from 32k rows
+    sym = (rp is cp and row0 == 0 and nrows == rp.n and rp.n < (1 << 27) and cap >= 2 and symenv != "0"
+           and (symenv == "1" or rp.n >= 32768))          # whole square graph: every unordered pair once
     counts = torch.empty(nrows, dtype=torch.int32, device=dev)
+    counts_lo = torch.empty(nrows, dtype=torch.int32, device=dev) if sym else None
     indptr = torch.empty(nrows + 1, dtype=torch.int64, device=dev)
     scratch = torch.empty(int(L.pg_scan_scratch_bytes(nrows)), dtype=torch.uint8, device=dev)
-    sym = os.environ.get("PG_EPS_SYM", "auto")               # 0 = never, 1 = whenever possible, auto = from 32k rows
-    if (rp is cp and row0 == 0 and nrows == rp.n and rp.n < (1 << 27) and cap >= 2 and sym != "0"
-            and (sym == "1" or rp.n >= 32768)):
-        # the whole square graph of one operand: every unordered pair once (pg_eps_slots_sym)
-        counts_lo = torch.empty(nrows, dtype=torch.int32, device=dev)
-        sargs = (_ptr(rp.buf), rp.npad, rp.n, rp.g * 32, bits, cmp, float(eps), cap, _ptr(slot_idx), _ptr(slot_w),
-                 _ptr(counts), _ptr(counts_lo))
-        _check(L.pg_eps_slots_sym(*sargs, _stream()), "pg_eps_slots_sym")
-        total = counts + counts_lo
+    budget = int(os.environ.get("PG_SLOT_BYTES_MAX", str(4 << 30)))
+    for attempt in (0, 1):
+        slot_idx = torch.empty(nrows * cap, dtype=torch.int32, device=dev)
+        slot_w = torch.empty(nrows * cap, dtype=torch.uint8, device=dev)
+        if sym:
+            args = (_ptr(rp.buf), rp.npad, rp.n, rp.g * 32, bits, cmp, float(eps), cap, _ptr(slot_idx), _ptr(slot_w),
+                    _ptr(counts), _ptr(counts_lo))
+            _check(L.pg_eps_slots_sym(*args, _stream()), "pg_eps_slots_sym")
+            total = counts + counts_lo
+        else:
+            args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, bits, cmp, float(eps),
+                    cap, _ptr(slot_idx), _ptr(slot_w), _ptr(counts))
+            _check(L.pg_eps_slots(*args, _stream()), "pg_eps_slots")
+            total = counts
         _check(L.pg_exclusive_scan(_ptr(total), nrows, _ptr(indptr), _ptr(scratch), _stream()), "pg_exclusive_scan")
-        nnz = int(indptr[-1].item())
-        indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
-        weights = torch.empty(max(nnz, 1), dtype=torch.uint8, device=dev)[:nnz]
-        if nnz:
-            _check(L.pg_eps_compact_sym(*sargs, _ptr(indptr), _ptr(indices), _ptr(weights), _stream()),
-                   "pg_eps_compact_sym")
-        return indptr, indices, weights
-    args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, bits, cmp, float(eps), cap)
-    _check(L.pg_eps_slots(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _stream()), "pg_eps_slots")
-    _check(L.pg_exclusive_scan(_ptr(counts), nrows, _ptr(indptr), _ptr(scratch), _stream()), "pg_exclusive_scan")
-    nnz = int(indptr[-1].item())
+        over = total > cap
+        stats = torch.stack([indptr[-1], over.sum(), total.max().to(torch.int64)]).cpu()     # the one sync
+        nnz, n_over, mx = (int(v) for v in stats)
+        if attempt == 0 and n_over * 50 > nrows:
+            q = int(torch.kthvalue(total, max(1, int(0.995 * nrows))).values.item())
+            cap2 = min((max(q, 2 * cap) + 63) // 64 * 64, (mx + 63) // 64 * 64, max(cap, budget // (5 * nrows)))
+            if cap2 > cap:
+                cap = cap2
+                del slot_idx, slot_w
+                continue
+        break
     indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
     weights = torch.empty(max(nnz, 1), dtype=torch.uint8, device=dev)[:nnz]
     if nnz:
-        _check(L.pg_eps_compact(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _ptr(indptr), _ptr(indices),
-                                _ptr(weights), _stream()), "pg_eps_compact")
+        if sym:
+            _check(L.pg_eps_compact_sym(*args, _ptr(indptr), _ptr(indices), _ptr(weights), _stream()), "pg_eps_compact_sym")
+        else:
+            _check(L.pg_eps_compact(*args, _ptr(indptr), _ptr(indices), _ptr(weights), _stream()), "pg_eps_compact")
     return indptr, indices, weights
 
 
