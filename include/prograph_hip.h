@@ -217,7 +217,11 @@ int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int bits,
  *   pg_lev_knn         exact banded edit distance per candidate (bit-parallel diagonal band) +
  *                      canonical kNN selection; `planes128` = the same tokens packed with
  *                      pg_pack_planes(bits = 5) at width l = 128 (chunk p = bit plane p);
- *                      counts_lo = NULL for pg_lev_candidates slots, else the symmetric pair
+ *                      counts_lo = NULL for pg_lev_candidates slots, else the symmetric pair.
+ *                      slot_aux (int32 [n*cap], optional, filled by pg_lev_candidates_sym) holds for
+ *                      every front entry the position of its mirror entry: with it and slot_w
+ *                      (scratch, uint8 [n*cap]) every candidate PAIR is evaluated once and the
+ *                      distance stored with both entries before the selection runs
  */
 int pg_lev_profile(const uint8_t *tokens, int64_t n, int l, int64_t ld, void *profiles,
                    int64_t npad, int32_t *lens, uint32_t *flags, void *stream);
@@ -225,12 +229,13 @@ int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row
                       int band, int cap, int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts,
                       void *stream);
 int pg_lev_candidates_sym(const void *profiles, int64_t npad, int64_t n, int band, int cap,
-                          int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts_up, uint32_t *counts_lo,
-                          void *stream);
+                          int32_t *slot_idx, uint8_t *slot_w, int32_t *slot_aux, uint32_t *counts_up,
+                          uint32_t *counts_lo, void *stream);
 int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const void *planes128,
                int64_t npad, const int32_t *lens, int64_t row0, int64_t nrows, int band, int k,
-               int cap, const int32_t *slot_idx, const uint32_t *counts, const uint32_t *counts_lo,
-               int32_t *idx_out, uint8_t *dist_out, void *stream);
+               int cap, const int32_t *slot_idx, uint8_t *slot_w, const int32_t *slot_aux,
+               const uint32_t *counts, const uint32_t *counts_lo, int32_t *idx_out, uint8_t *dist_out,
+               void *stream);
 
 /*
  * pg_csr_row_stats — per-row reductions over a CSR graph for the analytics that consume the

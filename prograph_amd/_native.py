@@ -93,9 +93,9 @@ def _load():
         lib.pg_csr_row_stats.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]
         lib.pg_lev_profile.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp]
         lib.pg_lev_candidates.argtypes = [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]
-        lib.pg_lev_candidates_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]
+        lib.pg_lev_candidates_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_lev_knn.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
-                                   _vp, _vp]
+                                   _vp, _vp, _vp, _vp]
         for name in SYMBOLS:
             fn = getattr(lib, name)
             if fn.restype is ctypes.c_int and name not in ("pg_version",):
@@ -429,9 +429,10 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
         passes += 1
         slot_idx = torch.empty(nrows * cap, dtype=torch.int32, device=dev)
         slot_w = torch.empty(nrows * cap, dtype=torch.uint8, device=dev)
+        slot_aux = torch.empty(nrows * cap, dtype=torch.int32, device=dev) if sym else None
         if sym:
             _check(L.pg_lev_candidates_sym(_ptr(prof), np_, n, int(band), int(cap), _ptr(slot_idx), _ptr(slot_w),
-                                           _ptr(counts), _ptr(counts_lo), _stream()), "pg_lev_candidates_sym")
+                                           _ptr(slot_aux), _ptr(counts), _ptr(counts_lo), _stream()), "pg_lev_candidates_sym")
             mx = int((counts + counts_lo).max().item())
         else:
             _check(L.pg_lev_candidates(_ptr(prof), np_, n, row0, nrows, int(band), int(cap), _ptr(slot_idx),
@@ -444,7 +445,8 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
     dist = torch.empty((nrows, k), dtype=torch.uint8, device=dev)
     _check(L.pg_lev_knn(_ptr(tokens), n, l, tokens.stride(0), _ptr(planes.buf), planes.npad, _ptr(lens), row0, nrows,
                         int(band), int(k), int(cap),
-                        _ptr(slot_idx), _ptr(counts), _ptr(counts_lo), _ptr(idx), _ptr(dist), _stream()), "pg_lev_knn")
+                        _ptr(slot_idx), _ptr(slot_w), _ptr(slot_aux), _ptr(counts), _ptr(counts_lo), _ptr(idx), _ptr(dist),
+                        _stream()), "pg_lev_knn")
     if return_stats:
         ncand = int(counts.to(torch.int64).sum().item()) + (int(counts_lo.to(torch.int64).sum().item()) if sym else 0)
         return idx, dist, {"candidates": ncand, "cap": cap, "filter_passes": passes, "symmetric": bool(sym)}

@@ -643,7 +643,7 @@ int pg_lev_candidates(const void *profiles, int64_t npad, int64_t n, int64_t row
 // Symmetric candidate generation (all rows against the same profiles): every unordered pair once,
 // the row itself excluded; slots as in pg_eps_slots_sym.  pg_lev_knn takes both counters.
 int pg_lev_candidates_sym(const void *profiles, int64_t npad, int64_t n, int band, int cap, int32_t *slot_idx,
-                          uint8_t *slot_w, uint32_t *counts_up, uint32_t *counts_lo, void *stream) {
+                          uint8_t *slot_w, int32_t *slot_aux, uint32_t *counts_up, uint32_t *counts_lo, void *stream) {
   if (!profiles || !slot_idx || !slot_w || !counts_up || !counts_lo || n <= 0 || cap < 0)
     return fail(PG_E_BADARG, "pg_lev_candidates_sym: bad argument");
   if (band < 0 || band > PG_LEV_MAX_BAND) return fail(PG_E_BADARG, "pg_lev_candidates_sym: band must be in 0..8");
@@ -655,7 +655,7 @@ int pg_lev_candidates_sym(const void *profiles, int64_t npad, int64_t n, int ban
   p.colPlanes = (const uint4 *)profiles; p.colNpad = npad; p.ncols = n;
   p.lo = 0; p.span = 2u * (u32)band; p.hi1 = p.span + 1u;
   p.filter = lb_filter_mode();
-  p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts_up; p.countsLo = counts_lo;
+  p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.slotAux = slot_aux; p.counts = counts_up; p.countsLo = counts_lo;
   hipError_t e = hipMemsetAsync(counts_lo, 0, (size_t)n * sizeof(uint32_t), (hipStream_t)stream);
   if (e != hipSuccess) return hipfail(e, "hipMemsetAsync");
   long long r = (n / 12500 + 3) / 4 * 4;                    // as pg_eps_slots_sym
@@ -668,8 +668,8 @@ int pg_lev_candidates_sym(const void *profiles, int64_t npad, int64_t n, int ban
 
 int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const void *planes128, int64_t npad,
                const int32_t *lens, int64_t row0, int64_t nrows,
-               int band, int k, int cap, const int32_t *slot_idx, const uint32_t *counts, const uint32_t *counts_lo,
-               int32_t *idx_out, uint8_t *dist_out, void *stream) {
+               int band, int k, int cap, const int32_t *slot_idx, uint8_t *slot_w, const int32_t *slot_aux,
+               const uint32_t *counts, const uint32_t *counts_lo, int32_t *idx_out, uint8_t *dist_out, void *stream) {
   if (!tokens || !planes128 || npad < n || npad % 256 || !lens || !slot_idx || !counts || !idx_out || !dist_out || n <= 0 || nrows <= 0 || row0 < 0 ||
       row0 + nrows > n || ld < l || cap < 0)
     return fail(PG_E_BADARG, "pg_lev_knn: bad argument");
@@ -678,8 +678,8 @@ int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const void *
   if (k < 1 || k > PG_MAX_K) return fail(PG_E_BADARG, "pg_lev_knn: k must be in 1..63");
   if (n > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_lev_knn: n exceeds 2^24");
   if (counts_lo && (row0 != 0 || nrows != n)) return fail(PG_E_BADARG, "pg_lev_knn: symmetric slots cover all rows");
-  return launched(pg_launch_lev_select(tokens, n, l, ld, (const uint4 *)planes128, npad, lens, row0, nrows, band, k, (u32)cap, slot_idx, counts,
-                                       counts_lo, idx_out, dist_out, (hipStream_t)stream), "pg_lev_select_kernel");
+  return launched(pg_launch_lev_select(tokens, n, l, ld, (const uint4 *)planes128, npad, lens, row0, nrows, band, k, (u32)cap, slot_idx, slot_w,
+                                       slot_aux, counts, counts_lo, idx_out, dist_out, (hipStream_t)stream), "pg_lev_select_kernel");
 }
 
 int pg_csr_row_stats(const int64_t *indptr, const int32_t *indices, const uint8_t *weights_u8, const float *weights_f32,

@@ -212,6 +212,7 @@ struct NsqParams {
   unsigned char *slotW;
   u32 *counts;
   u32 *countsLo;  // EPS_SYM: per row, matches found from the other side (column < row), filled with atomics
+  int *slotAux;   // EPS_SYM, optional: for a front entry the back position of its mirror entry in the other row's slot
   // knn: lanes [knnFirst, knnFirst + k) of the sorted 64-key list are written; keys <= floorKeys[row]
   // are ignored (continuation rounds for k > 63); lastKeys[row] receives the last written key
   int k, knnFirst;
@@ -253,5 +254,5 @@ int pg_launch_lev_profile(const unsigned char *tok, long long n, int l, long lon
                           int *lens, u32 *flags, hipStream_t s);
 int pg_launch_lev_select(const unsigned char *tok, long long n, int l, long long ld, const uint4 *planes,
                          long long npad, const int *lens, long long row0,
-                         long long nrows, int band, int k, u32 cap, const int *slotIdx, const u32 *counts, const u32 *countsLo,
+                         long long nrows, int band, int k, u32 cap, const int *slotIdx, unsigned char *slotW, const int *slotAux, const u32 *counts, const u32 *countsLo,
                          int *knnIdx, unsigned char *knnDist, hipStream_t s);

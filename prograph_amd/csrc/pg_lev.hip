@@ -89,6 +89,8 @@ struct LevParams {
   int band, k;
   u32 cap;
   const int *slotIdx;
+  unsigned char *slotW;  // phases 1/2: the exact distance of every candidate entry (both halves of a pair)
+  const int *slotAux;    // phase 1: back position of a front entry's mirror (pg_lev_candidates_sym)
   const u32 *counts;
   const u32 *countsLo;   // symmetric candidate slots (pg_lev_candidates_sym): entries found from the other side, or null
   int *knnIdx;
@@ -109,6 +111,12 @@ struct LevParams {
 // Eq comes from b's five 128-bit planes: the window is a funnel shift (v_alignbit) of two
 // adjacent plane dwords, and "plane bit equals a's bit" is folded with v_bitop3 against a mask
 // (0 / ~0 per plane of a[j]) that the wave precomputes once per row in LDS.
+// PHASE 0: distances + selection in one go (rectangular candidate slots, or symmetric ones without
+// the mirror table).  With symmetric slots and the mirror table every candidate PAIR is evaluated
+// once: PHASE 1 computes the distance of each front entry (column > row) and stores it with the
+// entry and with its mirror entry in the other row's slot; PHASE 2 only selects from the stored
+// distances.
+template <int PHASE>
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_lev_select_kernel(const LevParams p) {
   __shared__ uint4 amask[PG_WG_WAVES][PG_LEV_MAXL][2];   // per text position: masks of planes 0..3 | plane 4
   __shared__ u32 ldsF[PG_WG_WAVES][64];
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_lev_select_kernel(const LevP
   const u32 wbits = 2u * (u32)B + 1u;
   const u32 top = 1u << (wbits - 1u);
 
-  for (int j = lane; j < PG_LEV_MAXL; j += 64) {
+  for (int j = lane; PHASE != 2 && j < PG_LEV_MAXL; j += 64) {
     const u32 t = j < p.l ? (u32)p.tok[row * p.ld + j] : 0u;
     amask[wv][j][0] = make_uint4(0u - (t & 1u), 0u - ((t >> 1) & 1u), 0u - ((t >> 2) & 1u), 0u - ((t >> 3) & 1u));
     amask[wv][j][1] = make_uint4(0u - ((t >> 4) & 1u), 0u, 0u, 0u);
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_lev_select_kernel(const LevP
   const u32 up = p.counts[lr];
   const u32 lo = p.countsLo ? p.countsLo[lr] : 0u;
   if (p.countsLo && lane == 0) lst = (u32)row;
-  const u32 cnt = up + lo;
+  const u32 cnt = PHASE == 1 ? up : up + lo;           // phase 1 walks the front entries only
   const u32 ncand = cnt < p.cap ? cnt : p.cap;         // host guarantees cnt <= cap (re-runs otherwise)
 
   for (u32 c0 = 0; c0 < ncand; c0 += 64) {
@@ -148,56 +156,69 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_lev_select_kernel(const LevP
     const u32 ci = c0 + lane;
     const u32 spos = ci < up ? ci : p.cap - 1u - (ci - up);
     const int col = have ? p.slotIdx[lr * (long long)p.cap + spos] : 0;
-    const int lb = have ? p.lens[col] : 0;
-    u32 P[5][6];                                        // plane p as dwords [zero, w0, w1, w2, w3, zero]
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const uint4 v = p.planes[(long long)q * p.npad + col];
-      P[q][0] = 0u; P[q][1] = v.x; P[q][2] = v.y; P[q][3] = v.z; P[q][4] = v.w; P[q][5] = 0u;
-    }
-    const int kf = lb - la;
-    const bool done = !have || kf > B || kf < -B;
-    const u32 rbit = (u32)(B + (done ? 0 : kf));
-    u32 VP = ((1u << wbits) - 1u) & ~((1u << B) - 1u);
-    u32 VN = (1u << B) - 1u;
-    u32 zsum = 0;                                       // number of columns with D0[rbit] = 1
-    bool alive = true;                                  // some lane can still end within the band
-    // window start in the zero-extended 192-bit plane: bit offset j - B - 1 + 32 (>= 24)
-#pragma unroll
-    for (int seg = 0; seg < 5; ++seg) {
-      int j0 = 32 * seg - 31 + B, j1 = 32 * seg + B;
-      if (j0 < 1) j0 = 1;
-      if (j1 > la) j1 = la;
-      for (int j = j0; j <= j1 && alive; ++j) {
-        const u32 sh = (u32)(j - B - 1 + 32) & 31u;
-        const uint4 m03 = am[(j - 1) * 2];
-        const u32 m4 = am[(j - 1) * 2 + 1].x;
-        const u32 mk[5] = {m03.x, m03.y, m03.z, m03.w, m4};
-        u32 Eq = ~(__builtin_amdgcn_alignbit(P[0][seg + 1], P[0][seg], sh) ^ mk[0]);
-#pragma unroll
-        for (int q = 1; q < 5; ++q) {
-          const u32 wq = __builtin_amdgcn_alignbit(P[q][seg + 1], P[q][seg], sh);
-          Eq = __builtin_amdgcn_bitop3_b32(Eq, wq, mk[q], 0x90);       // Eq & ~(wq ^ mk)
-        }
-        const u32 t = (Eq & VP) + VP;
-        const u32 D0 = __builtin_amdgcn_bitop3_b32(t, VP, Eq, 0xBE) | VN;       // ((t ^ VP) | Eq) | VN
-        const u32 HP = __builtin_amdgcn_bitop3_b32(VN, D0, VP, 0xF1);  // VN | ~(D0 | VP)
-        const u32 HN = D0 & VP;
-        const u32 X = __builtin_amdgcn_ubfe(D0, 1u, wbits - 1u);
-        VN = X & HP;
-        VP = __builtin_amdgcn_bitop3_b32(HN, X, HP, 0xF1) | top;       // HN | ~(X | HP) | top
-        zsum += __builtin_amdgcn_ubfe(D0, rbit, 1u);
-        if ((j & 7) == 0) {
-          // the diagonal value never decreases: stop once no live lane can stay within the band
-          const u32 cur = (u32)(kf < 0 ? -kf : kf) + (u32)j - zsum;
-          alive = __builtin_amdgcn_ballot_w64(!done && cur <= (u32)B) != 0;
+    u32 result = capd;
+    const long long sidx = lr * (long long)p.cap + spos;
+    if constexpr (PHASE == 2) {
+      if (have) result = p.slotW[sidx];                 // stored by phase 1 (through this entry or its mirror)
+    } else {
+      const int lb = have ? p.lens[col] : 0;
+      u32 P[5][6];                                        // plane p as dwords [zero, w0, w1, w2, w3, zero]
+  #pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const uint4 v = p.planes[(long long)q * p.npad + col];
+        P[q][0] = 0u; P[q][1] = v.x; P[q][2] = v.y; P[q][3] = v.z; P[q][4] = v.w; P[q][5] = 0u;
+      }
+      const int kf = lb - la;
+      const bool done = !have || kf > B || kf < -B;
+      const u32 rbit = (u32)(B + (done ? 0 : kf));
+      u32 VP = ((1u << wbits) - 1u) & ~((1u << B) - 1u);
+      u32 VN = (1u << B) - 1u;
+      u32 zsum = 0;                                       // number of columns with D0[rbit] = 1
+      bool alive = true;                                  // some lane can still end within the band
+      // window start in the zero-extended 192-bit plane: bit offset j - B - 1 + 32 (>= 24)
+  #pragma unroll
+      for (int seg = 0; seg < 5; ++seg) {
+        int j0 = 32 * seg - 31 + B, j1 = 32 * seg + B;
+        if (j0 < 1) j0 = 1;
+        if (j1 > la) j1 = la;
+        for (int j = j0; j <= j1 && alive; ++j) {
+          const u32 sh = (u32)(j - B - 1 + 32) & 31u;
+          const uint4 m03 = am[(j - 1) * 2];
+          const u32 m4 = am[(j - 1) * 2 + 1].x;
+          const u32 mk[5] = {m03.x, m03.y, m03.z, m03.w, m4};
+          u32 Eq = ~(__builtin_amdgcn_alignbit(P[0][seg + 1], P[0][seg], sh) ^ mk[0]);
+  #pragma unroll
+          for (int q = 1; q < 5; ++q) {
+            const u32 wq = __builtin_amdgcn_alignbit(P[q][seg + 1], P[q][seg], sh);
+            Eq = __builtin_amdgcn_bitop3_b32(Eq, wq, mk[q], 0x90);       // Eq & ~(wq ^ mk)
+          }
+          const u32 t = (Eq & VP) + VP;
+          const u32 D0 = __builtin_amdgcn_bitop3_b32(t, VP, Eq, 0xBE) | VN;       // ((t ^ VP) | Eq) | VN
+          const u32 HP = __builtin_amdgcn_bitop3_b32(VN, D0, VP, 0xF1);  // VN | ~(D0 | VP)
+          const u32 HN = D0 & VP;
+          const u32 X = __builtin_amdgcn_ubfe(D0, 1u, wbits - 1u);
+          VN = X & HP;
+          VP = __builtin_amdgcn_bitop3_b32(HN, X, HP, 0xF1) | top;       // HN | ~(X | HP) | top
+          zsum += __builtin_amdgcn_ubfe(D0, rbit, 1u);
+          if ((j & 7) == 0) {
+            // the diagonal value never decreases: stop once no live lane can stay within the band
+            const u32 cur = (u32)(kf < 0 ? -kf : kf) + (u32)j - zsum;
+            alive = __builtin_amdgcn_ballot_w64(!done && cur <= (u32)B) != 0;
+          }
         }
       }
+      if (!done && alive) {
+        const u32 v = (u32)(kf < 0 ? -kf : kf) + (u32)la - zsum;
+        result = v < capd ? v : capd;
+      }
     }
-    u32 result = capd;
-    if (!done && alive) {
-      const u32 v = (u32)(kf < 0 ? -kf : kf) + (u32)la - zsum;
-      result = v < capd ? v : capd;
+    if constexpr (PHASE == 1) {
+      if (have) {
+        p.slotW[sidx] = (unsigned char)result;
+        const u32 pb = (u32)p.slotAux[sidx];
+        if (pb < p.cap) p.slotW[(long long)col * p.cap + (p.cap - 1u - pb)] = (unsigned char)result;
+      }
+      continue;
     }
 
     // candidates arrive in ascending column order: same sorted insertion as the Hamming kNN
@@ -218,6 +239,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_lev_select_kernel(const LevP
     }
   }
 
+  if constexpr (PHASE == 1) return;
   // ranks not filled by in-band candidates go to the smallest column indices at distance band+1
   // (all in-band columns are already in the list when it is not full, so "not a list member"
   // is the whole test).  All quantities below are wave uniform.
@@ -256,11 +278,19 @@ int pg_launch_lev_profile(const unsigned char *tok, long long n, int l, long lon
 
 int pg_launch_lev_select(const unsigned char *tok, long long n, int l, long long ld, const uint4 *planes,
                          long long npad, const int *lens, long long row0,
-                         long long nrows, int band, int k, u32 cap, const int *slotIdx, const u32 *counts, const u32 *countsLo,
+                         long long nrows, int band, int k, u32 cap, const int *slotIdx, unsigned char *slotW,
+                         const int *slotAux, const u32 *counts, const u32 *countsLo,
                          int *knnIdx, unsigned char *knnDist, hipStream_t s) {
   LevParams p;
   p.tok = tok; p.n = n; p.ld = ld; p.l = l; p.planes = planes; p.npad = npad; p.lens = lens; p.row0 = row0; p.nrows = nrows;
-  p.band = band; p.k = k; p.cap = cap; p.slotIdx = slotIdx; p.counts = counts; p.countsLo = countsLo; p.knnIdx = knnIdx; p.knnDist = knnDist;
-  pg_lev_select_kernel<<<dim3((unsigned)((nrows + PG_WG_WAVES - 1) / PG_WG_WAVES)), dim3(PG_WG_THREADS), 0, s>>>(p);
+  p.band = band; p.k = k; p.cap = cap; p.slotIdx = slotIdx; p.slotW = slotW; p.slotAux = slotAux; p.counts = counts;
+  p.countsLo = countsLo; p.knnIdx = knnIdx; p.knnDist = knnDist;
+  const dim3 grid((unsigned)((nrows + PG_WG_WAVES - 1) / PG_WG_WAVES)), block(PG_WG_THREADS);
+  if (countsLo && slotAux && slotW) {                   // every candidate pair once, then selection only
+    pg_lev_select_kernel<1><<<grid, block, 0, s>>>(p);
+    pg_lev_select_kernel<2><<<grid, block, 0, s>>>(p);
+  } else {
+    pg_lev_select_kernel<0><<<grid, block, 0, s>>>(p);
+  }
   return (int)hipGetLastError();
 }

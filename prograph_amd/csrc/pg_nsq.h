@@ -150,10 +150,11 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
     // wave, so its entry goes to the BACK of its slot (position from an atomic counter, any order;
     // pg_compact_sym_kernel sorts that part) while the owner fills the front in column order.  Front
     // and back can only collide when the row overflows its slot, and then it is recomputed anyway.
-    auto emit_lower = [&](bool on, u32 rowg, u32 col, u32 w) {
+    auto emit_lower = [&](bool on, u32 rowg, u32 col, u32 w) -> u32 {   // returns the back position
+      u32 pos = 0xFFFFFFFFu;
       if constexpr (kSym) {
         if (on) {
-          const u32 pos = atomicAdd(&p.countsLo[col], 1u);
+          pos = atomicAdd(&p.countsLo[col], 1u);
           if (pos < p.cap) {
             const long long o = (long long)col * p.cap + (p.cap - 1u - pos);
             p.slotIdx[o] = (int)rowg;
@@ -161,6 +162,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
           }
         }
       }
+      return pos;
     };
     auto epilogue = [&](u32 d, u32 col, int rr) {
       if constexpr (kEps) {
@@ -170,13 +172,16 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
         if (m2) {
           const u32 cnt = __builtin_amdgcn_readlane(cntv, rr);
           const u32 pos = cnt + mask_rank(m2);
+          const u32 posb = emit_lower(h2, (u32)(pr0 + rr), col, d + p.lo);
           if (h2 && pos < p.cap) {
             const long long o = (pr0 + rr) * (long long)p.cap + pos;
             p.slotIdx[o] = (int)col;
             p.slotW[o] = (unsigned char)(d + p.lo);
+            if constexpr (kSym) {
+              if (p.slotAux) p.slotAux[o] = (int)posb;
+            }
           }
           cntv = (lane == rr) ? cnt + (u32)__popcll(m2) : cntv;
-          emit_lower(h2, (u32)(pr0 + rr), col, d + p.lo);
         }
       } else {
         u32 thr = __builtin_amdgcn_readlane(thrv, rr);
@@ -281,7 +286,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
         }
         bool match = act && d <= p.span;
         if constexpr (kSym) match = match && col > (u32)pr0 + erow;
-        emit_lower(match, (u32)pr0 + erow, col, d + p.lo);
+        const u32 posb = emit_lower(match, (u32)pr0 + erow, col, d + p.lo);
         u64 m = __builtin_amdgcn_ballot_w64(match);
         while (m) {                                          // one turn per row present in the batch
           const u32 row = __builtin_amdgcn_readlane(erow, __builtin_ctzll(m));
@@ -293,6 +298,9 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
             const long long o = (pr0 + row) * (long long)p.cap + pos;
             p.slotIdx[o] = (int)col;
             p.slotW[o] = (unsigned char)(d + p.lo);
+            if constexpr (kSym) {
+              if (p.slotAux) p.slotAux[o] = (int)posb;
+            }
           }
           cntv = (lane == (int)row) ? cnt + (u32)__popcll(same) : cntv;
           m &= ~same;
