@@ -486,10 +486,9 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
   // Rows near the top sweep almost everything, rows near the bottom almost nothing; workgroups are
   // dispatched in row order, i.e. longest first, which balances by itself once there are a few
   // waves per resident slot.  Measured (tools/eps_sym_probe.py): 8 rows per wave at N = 50k, 16 at
-  // N = 200k (more rows: too few waves to balance; fewer: the per-wave column stream shows).
+  // N = 100k .. 200k (more rows: too few waves to balance; fewer: the per-wave column stream shows).
   if (!getenv("PG_ROWS_PER_WAVE") && !getenv("PG_WAVES_PER_CU")) {
-    long long r = (n / 12500 + 3) / 4 * 4;
-    r = r < 8 ? 8 : (r > 16 ? 16 : r);
+    const long long r = n >= 80000 ? 16 : 8;
     p.rowsPerWave = (int)r; p.rowsPerPass = (int)r;
     grid = (int)(((n + r - 1) / r + PG_WG_WAVES - 1) / PG_WG_WAVES);
   } else if (int rc = plan_rows(n, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS_SYM, bits), 16.0 * pg_nchunks(l, bits), 16)) {
@@ -658,8 +657,7 @@ int pg_lev_candidates_sym(const void *profiles, int64_t npad, int64_t n, int ban
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.slotAux = slot_aux; p.counts = counts_up; p.countsLo = counts_lo;
   hipError_t e = hipMemsetAsync(counts_lo, 0, (size_t)n * sizeof(uint32_t), (hipStream_t)stream);
   if (e != hipSuccess) return hipfail(e, "hipMemsetAsync");
-  long long r = (n / 12500 + 3) / 4 * 4;                    // as pg_eps_slots_sym
-  r = r < 8 ? 8 : (r > 16 ? 16 : r);
+  long long r = n >= 80000 ? 16 : 8;                        // as pg_eps_slots_sym
   if (const char *ev = getenv("PG_ROWS_PER_WAVE")) { if (atoi(ev) > 0) r = atoi(ev); }
   p.rowsPerWave = (int)r; p.rowsPerPass = (int)(r > PG_RB ? PG_RB : r);
   const int grid = (int)(((n + r - 1) / r + PG_WG_WAVES - 1) / PG_WG_WAVES);

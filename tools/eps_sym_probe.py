@@ -18,7 +18,7 @@ for N, L, eps in ((50000, 32, 2), (200000, 64, 2), (200000, 64, 1), (100000, 128
     res = []
     for sym in ("0", "1"):
         os.environ["PG_EPS_SYM"] = sym
-        for rpw in ("0", "8", "12", "16", "24", "32"):
+        for rpw in ("0", "4", "8", "12", "16", "24"):
             if sym == "0" and rpw != "0": continue
             if rpw == "0": os.environ.pop("PG_ROWS_PER_WAVE", None)
             else: os.environ["PG_ROWS_PER_WAVE"] = rpw
