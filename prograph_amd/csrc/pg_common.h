@@ -12,9 +12,13 @@ typedef unsigned long long u64;
 #define PG_RB 32    // rows per wave pass of the all-pairs engine (<= 64: per-row state is lane indexed)
 #define PG_RB_KNN 28 // kNN passes: 28 rows, so that lists + candidate queue keep 4 workgroups per CU in LDS
 #define PG_SORT_MAX 512 // symmetric eps: a row's back part (entries from lower rows) up to this size is rank-sorted in LDS
+#ifndef PG_QCAP
 #define PG_QCAP 128  // kNN: entries of the per-wave candidate queue (flushed in batches of 64)
+#endif
 #define PG_QCAP_EPS 576 // eps: every passing lane is queued (order!), a group can add 4 rows x 2 x 64
+#ifndef PG_PUSH_MAX
 #define PG_PUSH_MAX 8 // kNN: a triggered sub-tile with more passing lanes than this is evaluated in place
+#endif
 #define PG_RBD 64   // rows per workgroup of the dense kernel
 
 enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1, PG_MODE_EPS_SYM = 2 };   // EPS_SYM: square self-graph, upper triangle only
