@@ -248,9 +248,31 @@ class Prograph:
             self._planes[key] = planes
         return planes
 
+    def _planes_or_none(self):
+        """The cached plane layout, or None when the token matrix is beyond the fused kernels' limits
+        (more than 255 positions, 128 for alphabets above 31 symbols): the queries below then run on
+        the native dense operator (`hamming`, any length) plus torch ops on the GPU."""
+        try:
+            return self._byte_planes()
+        except (ValueError, TypeError):
+            return None
+
+    def _tokens_dev(self):
+        if getattr(self, "_tok_dev", None) is None:
+            self._tok_dev = torch.as_tensor(np.ascontiguousarray(self.tokenized), device=_native.device())
+        return self._tok_dev
+
+    def _row_distances_long(self, ref):
+        """(N,) int64 Hamming distances of every sequence to row `ref`, long-sequence path."""
+        T = self._tokens_dev()
+        return hamming(T, T[ref:ref + 1]).reshape(-1)
+
     def _distance_histogram(self, reference_seq):
-        planes = self._byte_planes()
-        _, hist, _ = _native.index_flags(planes, int(self.query(reference_seq)), want_dist_out=False, want_flags=False)
+        planes = self._planes_or_none()
+        ref = int(self.query(reference_seq))
+        if planes is None:
+            return torch.bincount(self._row_distances_long(ref)).cpu().numpy()
+        _, hist, _ = _native.index_flags(planes, ref, want_dist_out=False, want_flags=False)
         return hist.cpu().numpy()
 
     # ------------------------------------------------------------------ indexing
@@ -272,17 +294,16 @@ class Prograph:
         if reference_seq is None:
             reference_seq = self.seed.Sequence
         ref = int(self.query(reference_seq))
-        planes = self._byte_planes()
+        planes = self._planes_or_none()
 
         want = None
         if distances is not None:
             if type(distances) == int:
                 distances = [distances]
             assert type(distances) == list, "Distances must be provided as integer or list"
-            _, hist, _ = _native.index_flags(planes, ref, want_dist_out=False, want_flags=False)
-            hist = hist.cpu().numpy()
+            hist = self._distance_histogram(reference_seq)
             for d in distances:
-                assert isinstance(d, (int, np.integer)) and 0 <= d < 256 and hist[d] > 0, f"{d} is not a valid distance"
+                assert isinstance(d, (int, np.integer)) and 0 <= d < len(hist) and hist[d] > 0, f"{d} is not a valid distance"
             want = distances
 
         pos_mode, pos_mask, not_mask = 0, None, None
@@ -300,6 +321,20 @@ class Prograph:
 
         if want is None and pos_mode == 0:
             idxs = np.array(range(len(self)))
+        elif planes is None:
+            # long sequences: the same logic (reference :298-325) with torch ops on the GPU
+            T = self._tokens_dev()
+            keep = torch.ones(len(self), dtype=torch.bool, device=T.device)
+            if want is not None:
+                keep &= torch.isin(self._row_distances_long(ref), torch.as_tensor(want, device=T.device))
+            if pos_mode:
+                mut = T != T[ref:ref + 1]
+                sel = mut[:, pos_mask]
+                working = sel.any(dim=1) if pos_mode == 1 else sel.all(dim=1)
+                if not_mask:
+                    working &= ~mut[:, not_mask].any(dim=1)
+                keep &= working
+            idxs = torch.nonzero(keep).reshape(-1).cpu().numpy()
         else:
             _, _, flags = _native.index_flags(planes, ref, want=want, pos_mode=pos_mode, pos_mask=pos_mask,
                                               not_mask=not_mask, want_dist_out=False, want_hist=False)
@@ -319,8 +354,12 @@ class Prograph:
     def calc_neighbours(self, seq, eps=1, distance=hamming, comp=operator.eq, weights=False):
         """Column indices with comp(distance to `seq`, eps) (reference :526-544)."""
         if distance is hamming and comp in _CMP_CODE:
+            planes = self._planes_or_none()
+            if planes is None:
+                d = self._row_distances_long(int(self.query(seq)))
+                return torch.nonzero(comp(d, eps)).reshape(-1).cpu().numpy()
             want = [d for d in range(256) if comp(d, eps)]
-            _, _, flags = _native.index_flags(self._byte_planes(), int(self.query(seq)), want=want,
+            _, _, flags = _native.index_flags(planes, int(self.query(seq)), want=want,
                                               want_dist_out=False, want_hist=False)
             return _native.compact_flags(flags).cpu().numpy()
         d = distance(self.tokenized, self.tokenized[self.query(seq)].reshape(1, -1))
@@ -328,7 +367,11 @@ class Prograph:
 
     def neighbourhood(self, seq, eps, distance=hamming):
         """All rows within `eps` of `seq`, the row itself included (reference :571-588)."""
-        dist, _, _ = _native.index_flags(self._byte_planes(), int(self.query(seq)), want_hist=False, want_flags=False)
+        planes = self._planes_or_none()
+        if planes is None:
+            dist = self._row_distances_long(int(self.query(seq)))
+        else:
+            dist, _, _ = _native.index_flags(planes, int(self.query(seq)), want_hist=False, want_flags=False)
         return self[(dist <= eps).cpu().numpy().flatten()]
 
     def neighbourhood_clustering(self, eps, distance=hamming):
@@ -427,6 +470,10 @@ class Prograph:
         X = torch.as_tensor(np.vstack(self(representation)), dtype=torch.float16, device=dev)
         if idxs is not None:
             X = X[idxs, :]
+        if distance is hamming and len(X):
+            # our own operator (sequences beyond the fused engine's limits): batching does not change
+            # its result, so take row blocks of up to 2^26 distances instead of the reference's 8 rows
+            batch_size = max(batch_size, min(4096, (1 << 26) // len(X)))
         weights, edges = [], []
         if eps:
             for batch in self.get_every_n(X, n=batch_size):

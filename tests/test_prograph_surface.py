@@ -336,6 +336,53 @@ def test_constructor_on_synthetic_sets(backend, name, tmp_path, capsys):
 EMBEDDED = np.array([[0, 0], [0.5, 0], [4, 0], [3, 0], [4.2, 1.5], [4.95, 1.75]], dtype=np.float32)
 
 
+def test_sequences_beyond_the_fused_limits(backend, tmp_path, capsys):
+    """More than 255 positions: the reference has no length limit (its hamming() is a broadcast), the
+    fused kernels do.  Constructor, summary, indexing (distances / positions / both), calc_neighbours,
+    neighbourhood and build_graph (eps and k) must still work and agree with the oracle: they run on
+    the native dense operator, which sums column segments, plus torch ops."""
+    from oracle import prograph_oracle as O
+    from prograph_amd import Prograph
+    N, L = 400, 300
+    tok = synth.clustered_tokens(N, L, seed=12, members=40)
+    tok[5] = tok[45]                                           # a duplicate
+    f = tmp_path / "long.csv"
+    pd.DataFrame({"Sequence": synth.tokens_to_strings(tok), "Fitness": np.arange(N, dtype=float)}).to_csv(f)
+    pg = Prograph(file=str(f))
+    out = capsys.readouterr().out
+    t64 = tok.astype(np.int64)
+    d0 = O.hamming(t64, t64[:1]).numpy()[0]
+    assert f"Number of Sequences : {N}" in out and f"Max Distance        : {int(d0.max())}" in out
+    assert f"Number of Distances : {len(np.unique(d0))}" in out and f"Longest Sequence    : {L}" in out
+    # indexing: distances, positions (or / and), both, against the oracle's restatement
+    dd = [int(x) for x in np.unique(d0)[1:3]]
+    assert np.array_equal(pg.indexing(distances=dd), O.indexing(t64, 0, L, distances=dd))
+    mutpos = [int(x) for x in np.nonzero((t64 != t64[0]).any(axis=0))[0][:3]]
+    for mode in ("or", "and"):
+        try:
+            want = O.indexing(t64, 0, L, positions=mutpos, Bool=mode)
+        except AssertionError:
+            with pytest.raises(AssertionError):
+                pg.indexing(positions=mutpos, Bool=mode)
+            continue
+        assert np.array_equal(pg.indexing(positions=mutpos, Bool=mode), want)
+    with pytest.raises(AssertionError):
+        pg.indexing(distances=[L + 5])
+    seq7 = pg("Sequence")[7]
+    d7 = O.hamming(t64, t64[7:8]).numpy()[0]
+    assert np.array_equal(pg.calc_neighbours(seq7, eps=int(np.sort(d7)[3]), comp=operator.le), np.nonzero(d7 <= np.sort(d7)[3])[0])
+    assert list(pg.neighbourhood(seq7, 4).index) == list(np.nonzero(d7 <= 4)[0])
+    # graphs through the batch loop over the native dense operator
+    g = pg.build_graph(k=5)
+    e = pg.build_graph(eps=4)
+    for r in (0, 5, 45, 399):
+        d = O.hamming(t64, t64[r:r + 1]).numpy()[0]
+        order = np.argsort(d, kind="stable")[1:6]
+        assert np.array_equal(g[r][0], order) and np.array_equal(g[r][1], d[order])
+        cols = np.nonzero((d <= 4) & (d > 0))[0]
+        assert np.array_equal(e[r][0], cols) and np.array_equal(e[r][1], d[cols])
+
+
 @pytest.fixture
 def knn_test(backend, tmp_path, capsys):
     from prograph_amd import Prograph
