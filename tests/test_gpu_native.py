@@ -6,6 +6,8 @@ Bit-exact: everything on this path is integer work.
 """
 import operator
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -483,6 +485,19 @@ def test_knn_optimistic_cap_is_exact(nat, monkeypatch, guess):
     idx, d = nat.knn_graph(p, p, 8)
     ridx, rd = C.knn(tok, 8)
     assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
+
+
+def test_c_abi_without_python(nat):
+    """tests/capi/capi_check.cpp: a plain C++ host (hipMalloc, default stream, the declarations of
+    include/prograph_hip.h, no Python, no torch) drives pack -> kNN -> eps CSR through both the
+    rectangular and the symmetric entry points and compares with the C oracle."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "capi", "_build", "capi_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(here, "capi")])
+    out = subprocess.run([exe, "30000", "64"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "C ABI OK" in out.stdout, out.stdout + out.stderr
 
 
 def test_randomised_shapes_against_c_oracle(nat):
