@@ -533,6 +533,34 @@ def test_randomised_shapes_against_c_oracle(nat):
             assert np.array_equal(nat.hamming_dense(p, _planes(nat, tok[:m], bits)).cpu().numpy(), C.hamming(tok, tok[:m])), (it, N, L)
 
 
+def test_cfg5_full_size_properties(nat):
+    """BASELINE.json configs[4] at full size (N = 200 000, L <= 128, band 8, k = 8; build defined,
+    parity unpinned): ordering and range properties of every row, mutual consistency of the distances
+    (edit distance is symmetric), and sampled rows against the C oracle's banded Wagner-Fischer."""
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    N, k, band = 200_000, 8, 8
+    tok, lens = synth.clustered_varlen_tokens(N, Lmax=128, Lmin=96)
+    idx, d, st = nat.levenshtein_knn(torch.from_numpy(tok), k, band=band, return_stats=True)
+    idx, d = idx.cpu().numpy().astype(np.int64), d.cpu().numpy().astype(np.int64)
+    assert st["symmetric"] and idx.min() >= 0 and idx.max() < N and d.min() >= 0 and d.max() <= band + 1
+    key = d * (1 << 24) + idx
+    assert np.all(key[:, 1:] > key[:, :-1])                      # canonical (distance, column) order, no repeats
+    # rank 0 is dropped; a row can only meet itself again behind an exact duplicate with a smaller column
+    assert np.all(d[idx == np.arange(N)[:, None]] == 0)
+    # symmetry: if j is i's neighbour at distance x <= band and i appears in j's list, the distance agrees
+    rows = np.repeat(np.arange(N), k)
+    cols = idx.reshape(-1); dist = d.reshape(-1)
+    fwd = dict(zip(zip(rows[:200000].tolist(), cols[:200000].tolist()), dist[:200000].tolist()))
+    for (i, j), x in list(fwd.items())[:20000]:
+        back = np.nonzero(idx[j] == i)[0]
+        if len(back):
+            assert d[j, back[0]] == x
+    for r0 in (0, 77_777, N - 16):
+        ridx, rd = C.lev_knn(tok, k, band=band, row0=r0, nrows=16)
+        assert np.array_equal(idx[r0:r0 + 16], ridx) and np.array_equal(d[r0:r0 + 16], rd), r0
+
+
 def test_hamming_operator_cache_tracks_in_place_edits(nat):
     """hamming() remembers the packed form of a device-resident X across calls (the reference's
     batch loop passes the same X every time); an in-place edit of X must invalidate it."""
