@@ -8,9 +8,10 @@ from oracle import c_oracle as C
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"          # larger problems (the symmetric eps path switches on by itself)
 t0 = time.time()
 for it in range(iters):
-    N = int(rng.choice([300, 1000, 2500, 6000, 12000, 20000]))
+    N = int(rng.choice([40000, 60000, 90000])) if BIG else int(rng.choice([300, 1000, 2500, 6000, 12000, 20000]))
     amax = int(rng.choice([2, 4, 20, 31, 200]))
     L = int(rng.randint(4, 255 if amax <= 31 else 129))
     ncl = max(1, N // int(rng.choice([8, 24, 100, 400, 3000])))
@@ -27,7 +28,7 @@ for it in range(iters):
     bits = 5 if (amax <= 31 and (L > 128 or rng.rand() < 0.7)) else 8
     os.environ["PG_KNN_GUESS"] = str(rng.choice([0, 2, 5, 8, 8, 8, 20]))
     os.environ["PG_LB_FILTER"] = str(rng.choice([0, 1, 1, 1, 2]))
-    os.environ["PG_EPS_SYM"] = str(rng.choice([0, 1]))
+    os.environ["PG_EPS_SYM"] = "auto" if BIG else str(rng.choice([0, 1]))
     p = nat.pack(torch.from_numpy(tok), bits=bits)
     k = int(rng.choice([1, 5, 16, 40, 63, 90]))
     lo = int(rng.randint(0, N // 2)); nr = int(rng.randint(1, N - lo + 1)) if rng.rand() < 0.5 else None
@@ -45,6 +46,6 @@ for it in range(iters):
         print(f"MISMATCH it={it} N={N} L={L} amax={amax} bits={bits} k={k} eps={eps} cmp={cmp} cap={cap} row0={lo} nrows={nr} "
               f"guess={os.environ['PG_KNN_GUESS']} filter={os.environ['PG_LB_FILTER']} sym={os.environ['PG_EPS_SYM']} knn_ok={ok1} eps_ok={ok2}", flush=True)
         sys.exit(1)
-    if it % 20 == 0:
+    if it % (2 if BIG else 20) == 0:
         print(f"it {it} ok ({time.time() - t0:.0f}s) N={N} L={L} bits={bits} k={k}", flush=True)
 print(f"all {iters} iterations ok in {time.time() - t0:.0f}s")
