@@ -26,7 +26,11 @@
  * zero).  A 64-lane wavefront that owns 64 consecutive sequences therefore reads one chunk per
  * lane as a single fully coalesced 1 KiB `global_load_dwordx4`, and the Hamming distance of
  * two records is B+1 VALU instructions per 32 tokens (xor, v_bitop3 x (B-1), v_bcnt).
- * Buffer size: pg_nchunks(L, bits) * pg_npad(N) * 16 bytes.
+ * Behind the Q chunk arrays the buffer carries the SIGNATURE SECTION (32 * Npad bytes): per sequence
+ * the 31-bit filter signature (XOR fold of its plane-0 dwords) expanded to one byte per bit, per 32
+ * sequences one 1 KiB block in int8-MFMA fragment order - the column operand of the matrix-core
+ * filter stage of the all-pairs engine (prograph_amd/csrc/pg_mm.h).
+ * Buffer size: pg_planes_bytes(N, L, bits) = (pg_nchunks(L, bits) * 16 + 32) * pg_npad(N) bytes.
  */
 #ifndef PROGRAPH_HIP_H
 #define PROGRAPH_HIP_H
@@ -37,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 1
+#define PG_ABI_VERSION 2   /* 2: plane buffers carry the signature section */
 
 /* library error codes (negative return values) */
 #define PG_E_BADARG   (-1)   /* NULL pointer, negative size, k out of range ...        */
@@ -71,6 +75,8 @@ int         pg_device_info(int *cu_count, int *wave_size, char *arch, int arch_l
 int64_t     pg_npad(int64_t n);
 int         pg_ngroups(int l);
 int         pg_nchunks(int l, int bits);
+/* bytes of a plane buffer for n sequences of l tokens: chunk arrays + signature section */
+int64_t     pg_planes_bytes(int64_t n, int l, int bits);
 
 /*
  * pg_pack_planes — row-major tokens -> plane layout.
@@ -81,7 +87,7 @@ int         pg_nchunks(int l, int bits);
  *              `elem_bytes` in {1,2,4,8} (uint8 / int16 / int32 / int64 tokens)
  *   rows       optional int64[n] gather list (the reference's `idxs`), NULL = identity
  *   bits       PG_BITS_5 or PG_BITS_8
- *   planes     out, pg_nchunks(l,bits)*npad*16 bytes, fully overwritten (padding zeroed)
+ *   planes     out, pg_planes_bytes(n,l,bits) bytes, fully overwritten (padding zeroed)
  *   flags      out, uint32[1]: set to 1 when some token is outside 0..2^bits-1 (such tokens
  *              are truncated; the caller must not use the result)
  */

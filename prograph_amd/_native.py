@@ -17,7 +17,7 @@ import torch   # must be imported before the library is loaded: see _load()
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PROGRAPH_HIP_LIB: load another build of the same ABI (kernel A/B comparisons, tools/ab.py)
 LIB_PATH = os.environ.get("PROGRAPH_HIP_LIB") or os.path.join(_HERE, "libprograph_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 BITS_5, BITS_8 = 5, 8
 CMP_LE, CMP_LT, CMP_EQ, CMP_GE, CMP_GT = 0, 1, 2, 3, 4
@@ -25,7 +25,8 @@ MAX_L, MAX_L_5BIT, MAX_K, MAX_K_ROUNDS, MAX_N_KNN, LEV_MAX_BAND = 128, 255, 63, 
 
 # every symbol include/prograph_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_pack_planes",
+    "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_planes_bytes",
+    "pg_pack_planes",
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
     "pg_eps_compact", "pg_eps_slots_sym", "pg_eps_compact_sym", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
     "pg_lev_profile", "pg_lev_candidates", "pg_lev_candidates_sym", "pg_lev_knn", "pg_csr_row_stats",
@@ -72,6 +73,8 @@ def _load():
         lib.pg_ngroups.argtypes = [_i32]
         lib.pg_nchunks.restype = _i32
         lib.pg_nchunks.argtypes = [_i32, _i32]
+        lib.pg_planes_bytes.restype = _i64
+        lib.pg_planes_bytes.argtypes = [_i64, _i32, _i32]
         lib.pg_scan_scratch_bytes.restype = _i64
         lib.pg_scan_scratch_bytes.argtypes = [_i64]
         lib.pg_device_info.argtypes = [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32]
@@ -141,6 +144,11 @@ def nchunks(l, bits):
     return (ngroups(l) * int(bits) + 3) // 4
 
 
+def planes_bytes(n, l, bits):
+    """Chunk arrays + the 32-byte-per-sequence signature section (MFMA column operand)."""
+    return (nchunks(l, bits) * 16 + 32) * npad(n)
+
+
 class Planes:
     """Device-resident token matrix as bit-sliced records (see include/prograph_hip.h)."""
     __slots__ = ("buf", "n", "l", "npad", "g", "q", "bits")
@@ -202,7 +210,7 @@ def pack(tokens, rows=None, bits=None, width=None):
         wide = torch.zeros((n_src, lw), dtype=tokens.dtype, device=dev)   # clean_input's zero right-padding
         wide[:, :l] = tokens
         tokens = wide
-    buf = torch.empty(nchunks(lw, bits) * np_ * 16, dtype=torch.uint8, device=dev)
+    buf = torch.empty(planes_bytes(n, lw, bits), dtype=torch.uint8, device=dev)
     flags = torch.zeros(1, dtype=torch.int32, device=dev)
     _check(L.pg_pack_planes(_ptr(tokens), tokens.element_size(), n, lw, tokens.stride(0), _ptr(ridx), int(bits),
                             _ptr(buf), np_, _ptr(flags), _stream()), "pg_pack_planes")

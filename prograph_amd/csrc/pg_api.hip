@@ -1,6 +1,7 @@
 // C ABI of the hot path (include/prograph_hip.h) + the O(N*L) helper kernels:
 // plane packing, exclusive scan, flag compaction and the fused 1xN indexing pass.
 #include "pg_common.h"
+#include "pg_mm.h"
 #include "../../include/prograph_hip.h"
 
 #include <math.h>
@@ -66,6 +67,7 @@ int pg_device_info(int *cus, int *wave, char *arch, int arch_len) {
 int64_t pg_npad(int64_t n) { return n <= 0 ? 256 : ((n + 255) / 256) * 256; }
 int pg_ngroups(int l) { return l <= 0 ? 1 : (l + 31) / 32; }
 int pg_nchunks(int l, int bits) { return (pg_ngroups(l) * bits + 3) / 4; }
+int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunks(l, bits) * 16 + 32) * pg_npad(n); }
 
 }  // extern "C"
 
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
   if (s >= npad) return;
   const T *row = nullptr;
   if (s < n) row = src + (rows ? rows[s] : s) * ld;
-  u32 bad = 0;
+  u32 bad = 0, sig = 0;
   for (int g = 0; g < ng; ++g) {
     u32 pl[B];
 #pragma unroll
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
         }
       }
     }
+    sig ^= pl[0];                             // filter signature: XOR fold of the plane-0 words
 #pragma unroll
     for (int p = 0; p < B; ++p) {
       const int w = p * ng + g;               // plane-major record order
@@ -103,6 +106,17 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
     }
   }
   for (int w = ng * B; w < nq * 4; ++w) planes[((long long)(w >> 2) * npad + s) * 4 + (w & 3)] = 0;
+  // Signature section (after the nq chunk arrays): the column operand of the stage-1 MFMA
+  // (pg_mm.h), one byte per signature bit, per 32 sequences one 1 KiB block in fragment order:
+  // uint4 [tile][h * 32 + c] = bytes k = 16h .. 16h+15 of sequence 32 * tile + c; byte 31 is the
+  // constant 1 that multiplies the row's bias (0 for padding sequences: they never pass).
+  {
+    const u32 s31 = pg_sig31(sig);
+    uint4 *e = reinterpret_cast<uint4 *>(planes + (long long)nq * npad * 4) + (s >> 5) * 64 + (s & 31);
+    e[0] = make_uint4(pg_spread4(s31), pg_spread4(s31 >> 4), pg_spread4(s31 >> 8), pg_spread4(s31 >> 12));
+    e[32] = make_uint4(pg_spread4(s31 >> 16), pg_spread4(s31 >> 20), pg_spread4(s31 >> 24),
+                       pg_spread4(s31 >> 28) | (row ? 0x01000000u : 0u));
+  }
   if (bad) atomicOr(flags, bad);
 }
 
@@ -449,7 +463,31 @@ static int fill_nsq(NsqParams *p, const void *row_planes, int64_t row_npad, int6
   p->filter = lb_filter_mode();
   p->rowPlanes = (const uint4 *)row_planes; p->rowNpad = row_npad; p->row0 = row0; p->nrows = nrows;
   p->colPlanes = (const uint4 *)col_planes; p->colNpad = col_npad; p->ncols = ncols;
+  p->colSig = p->colPlanes + (long long)pg_nchunks(l, bits) * col_npad;
   return 0;
+}
+
+// Which all-pairs engine runs a Hamming launch: pg_mm.h (stage 1 on the matrix cores, passes of 32
+// rows per wave) or pg_nsq.h (stage 1 on the VALU, 4..32 rows per wave).  PG_ENGINE=mfma / valu forces one.
+// Auto: the MFMA engine from 8 waves per SIMD-column on, i.e. once 32-row passes fill the chip; below
+// that the VALU engine's finer row split keeps more CUs busy.
+static bool use_mm_engine(int64_t nrows) {
+  if (const char *e = getenv("PG_ENGINE")) {
+    if (!strcmp(e, "mfma")) return true;
+    if (!strcmp(e, "valu")) return false;
+  }
+  const long long thr = getenv("PG_ENGINE_MIN_ROWS") ? atoll(getenv("PG_ENGINE_MIN_ROWS")) : 65536;
+  return nrows >= thr;
+}
+static const nsq_fn kMm[8] = {pg_launch_mm_g1, pg_launch_mm_g2, pg_launch_mm_g3, pg_launch_mm_g4,
+                              pg_launch_mm_g5, pg_launch_mm_g6, pg_launch_mm_g7, pg_launch_mm_g8};
+// one pass of 32 rows per wave (PG_ROWS_PER_WAVE: whole passes)
+static void plan_mm(int64_t nrows, NsqParams *p, int *grid) {
+  long long rpw = PG_MM_RB;
+  if (const char *e = getenv("PG_ROWS_PER_WAVE")) { if (atoi(e) > 0) rpw = (atoi(e) + PG_MM_RB - 1) / PG_MM_RB * PG_MM_RB; }
+  p->rowsPerWave = (int)rpw; p->rowsPerPass = PG_MM_RB;
+  const long long waves = (nrows + rpw - 1) / rpw;
+  *grid = (int)((waves + PG_WG_WAVES - 1) / PG_WG_WAVES);
 }
 
 int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
@@ -463,6 +501,10 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
   p.hi1 = (p.lo > 0xFFFFFF00u - 1u) ? 0u : p.lo + p.span + 1u;   // empty interval: nothing can match
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
   int grid = 0;
+  if (use_mm_engine(nrows)) {
+    plan_mm(nrows, &p, &grid);
+    return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps)");
+  }
   if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS, bits), 16.0 * pg_nchunks(l, bits))) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(eps)");
 }
@@ -487,6 +529,10 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
   // dispatched in row order, i.e. longest first, which balances by itself once there are a few
   // waves per resident slot.  Measured (tools/eps_sym_probe.py): 8 rows per wave at N = 50k, 16 at
   // N = 100k .. 200k (more rows: too few waves to balance; fewer: the per-wave column stream shows).
+  if (use_mm_engine(n)) {
+    plan_mm(n, &p, &grid);
+    return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS_SYM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps sym)");
+  }
   if (!getenv("PG_ROWS_PER_WAVE") && !getenv("PG_WAVES_PER_CU")) {
     const long long r = n >= 80000 ? 16 : 8;
     p.rowsPerWave = (int)r; p.rowsPerPass = (int)r;
@@ -564,6 +610,10 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   if (p.filter == 0) p.knnGuess = 0;                       // no stage 1, nothing to cap
   p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;
+  if (use_mm_engine(nrows)) {
+    plan_mm(nrows, &p, &grid);
+    return launched(kMm[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn)");
+  }
   if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits), 16.0 * pg_nchunks(l, bits), PG_RB_KNN)) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");
 }

@@ -206,6 +206,7 @@ struct NsqParams {
   long long rowNpad, row0, nrows;
   const uint4 *colPlanes;
   long long colNpad, ncols;
+  const uint4 *colSig;  // signature section of the column operand: MFMA B fragments, 1 KiB per 32 columns (pg_mm.h)
   int rowsPerWave, rowsPerPass;
   int filter;   // 1 = plane-0 lower-bound filter allowed (adaptive per tile), 0 = always direct
   u32 knnGuess; // kNN: optimistic cap on the stage-1 bound until a row's list is full (0 = off), see pg_nsq.h
@@ -248,6 +249,7 @@ struct CompactParams {
 #define PG_DECL_G(G)                                                                          \
   int pg_launch_nsq_g##G(int mode, int bits, const NsqParams &p, int grid, hipStream_t s);   \
   int pg_occ_nsq_g##G(int mode, int bits); /* resident workgroups per CU of that instance */ \
+  int pg_launch_mm_g##G(int mode, int bits, const NsqParams &p, int grid, hipStream_t s); /* MFMA stage 1 (pg_mm.h) */ \
   int pg_launch_dense_g##G(int bits, const DenseParams &p, hipStream_t s);                    \
   int pg_launch_compact_g##G(int bits, const CompactParams &p, hipStream_t s);
 PG_DECL_G(1) PG_DECL_G(2) PG_DECL_G(3) PG_DECL_G(4) PG_DECL_G(5) PG_DECL_G(6) PG_DECL_G(7) PG_DECL_G(8)

@@ -1,0 +1,490 @@
+// The all-pairs engine, second generation: stage 1 (signature lower bound) on the MATRIX cores.
+//
+// Replaces the hot loop of Prograph.build_graph (prograph/prograph.py:731-739 and :756-762 of the
+// reference): distance(X, batch) -> mask/where or sort -> gather.  Same contract, same per-row
+// ownership and output order as pg_nsq.h (one wave owns a pass of rows and sweeps ALL columns in
+// ascending order, so eps matches come out in `torch.where` order and kNN lists need no merge);
+// what changed is how the ~97 % of pairs that cannot match are rejected.
+//
+// Stage 1 as an int8 MFMA.  The 31-bit filter signature of a sequence (XOR fold of its plane-0
+// words, pg_common.h) gives   lb(i,j) = popcount(s_i ^ s_j) <= d(i,j).   That popcount is bilinear:
+//     lb = pa_i - sum_k a'_ik * b_jk        a' = +1 / -1 per signature bit of the row,
+//                                           b  =  1 /  0 per signature bit of the column,
+// so with  A_ik = -a'_ik  (k < 31),  A_i,31 = pa_i - bound_i,  B_kj = b_jk,  B_31,j = 1
+//     D = A x B = lb(i,j) - bound_i,        "may be below the row's bound"  <=>  D < 0.
+// One v_mfma_i32_32x32x32_i8 evaluates 32 rows x 32 columns; the 16 result registers are OR-ed
+// (8 v_or3) and ONE sign test + scalar branch decides whether the tile holds any candidate:
+// ~0.17 VALU instructions per 64 pairs instead of ~2.9 (pg_nsq.h), with the 1024 multiply-adds on
+// a pipe the VALU does not compete for.  Measured on MI355X (tools/ubench/mfma_s1.hip, N = 200k
+// full sweep): 1.45 ms against 3.6 ms for the xor + bcnt form; insensitive to occupancy (2..8
+// waves per SIMD) and to how many row blocks share a column fragment, i.e. not bound by the
+// 1 KiB-per-MFMA fragment stream from L2.
+//   * the row operand A (4 VGPRs) is built once per pass and stays in registers; a row's bound is
+//     ONE byte of it (lane 32+row, top byte of A[3]) and is rewritten in place when the row's
+//     threshold moves (kNN) - no LDS traffic for bounds at all;
+//   * the column operand comes from the signature section of the plane buffer ("E", written by
+//     pg_pack_planes): per 32 columns one 1 KiB block in MFMA fragment order, so a B operand is a
+//     single coalesced global_load_dwordx4; a ring of four tiles is in flight;
+//   * candidates (D < 0) are queued as (row, column) in LDS and evaluated exactly 64 at a time, one
+//     per lane, with gathered records - as in pg_nsq.h, but now for every candidate (the column
+//     records are no longer in registers);
+//   * dense data (most pairs pass stage 1) switches a wave to the DIRECT form for a while: whole
+//     column records in registers, every exact distance computed (the form pg_nsq.h falls back
+//     to as well); the decision is per wave and per window of tiles.
+// kNN keeps the optimistic cap / checkpoint / second-phase scheme of pg_nsq.h (exactness argument
+// there and in DESIGN.md §4.1); only the representation of the bound changed.
+#pragma once
+#include "pg_common.h"
+
+typedef int pg_v4i __attribute__((ext_vector_type(4)));
+typedef int pg_v16i __attribute__((ext_vector_type(16)));
+
+#define PG_MM_RB 32          // rows per pass = M of the MFMA tile
+#define PG_MM_QCAP 128       // candidate queue entries per wave: < 64 before a push, <= 64 per push
+#define PG_MM_ST 128         // columns per super-tile: 4 MFMA tiles = one direct-form tile (C = 2)
+
+static_assert(PG_MM_QCAP >= 63 + 64, "a register push adds up to 64 candidates to a queue holding up to 63");
+static_assert(PG_QCAP >= 63 + 4 * 2 * PG_PUSH_MAX, "pg_nsq.h kNN queue: a group pushes up to 4 rows x 2 columns x PG_PUSH_MAX");
+static_assert(PG_QCAP_EPS >= 63 + 4 * 2 * 64, "pg_nsq.h eps queue: a group pushes up to 4 rows x 2 x 64 lanes");
+
+// 31-bit filter signature from the 32-bit XOR fold (bit 31 folds onto bit 0: still "an odd number
+// of the positions folded onto this bit differ", i.e. still a lower bound)
+__device__ __forceinline__ u32 pg_sig31(u32 s) { return (s ^ (s >> 31)) & 0x7FFFFFFFu; }
+
+// 4 signature bits -> 4 bytes with bit i in the LSB of byte i
+__device__ __forceinline__ u32 pg_spread4(u32 nib) { return ((nib & 0xFu) * 0x00204081u) & 0x01010101u; }
+
+// row operand bytes: bit set -> -1 (0xFF), bit clear -> +1 (0x01)
+__device__ __forceinline__ u32 pg_expand_pm1(u32 nib) { return 0x01010101u + pg_spread4(nib) * 0xFEu; }
+
+__device__ __forceinline__ int pg_or16(const pg_v16i &d) {
+  int a = d[0] | d[1] | d[2];
+  int b = d[3] | d[4] | d[5];
+  int c = d[6] | d[7] | d[8];
+  int e = d[9] | d[10] | d[11];
+  int f = d[12] | d[13] | d[14];
+  a = a | b | c;
+  e = e | f | d[15];
+  return a | e;
+}
+
+template <class M, int MODE>
+__global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p) {
+  constexpr int Q = M::Q;
+  constexpr int C = Q <= 4 ? 2 : 1;                        // direct form: columns per lane
+  constexpr bool kEps = MODE != PG_MODE_KNN;
+  constexpr bool kSym = MODE == PG_MODE_EPS_SYM;
+  constexpr int RB = PG_MM_RB;
+  constexpr int LROWS = MODE == PG_MODE_KNN ? RB : 1;
+  __shared__ uint4 rowbuf[PG_WG_WAVES][RB][Q];
+  __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
+  __shared__ u32 cqbuf[PG_WG_WAVES][PG_MM_QCAP];           // deferred candidates: row << SH | column
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
+  const long long wr0 = gw * p.rowsPerWave;
+  if (wr0 >= p.nrows) return;   // whole wave leaves; no workgroup barrier is used below
+  const long long wr1 = (wr0 + p.rowsPerWave < p.nrows) ? wr0 + p.rowsPerWave : p.nrows;
+  const uint4 *__restrict__ colp = p.colPlanes;
+  const pg_v4i *__restrict__ colsig = reinterpret_cast<const pg_v4i *>(p.colSig);
+  const u32 ncols = (u32)p.ncols;
+  const int nst = (int)((p.ncols + PG_MM_ST - 1) / PG_MM_ST);   // super-tiles of 128 columns
+  const uint4 *rows = &rowbuf[wv][0][0] + opaque_zero();   // broadcast reads, kept "divergent"
+  u32 *cq = &cqbuf[wv][0];
+  const u32 bias = kEps ? opaque_vgpr(0u - p.lo) : 0u;     // eps: -lo rides in the popcount accumulator
+  // eps entries carry the row in 5 bits above a 27-bit column; wider problems run the direct form
+  const bool canFilter = p.filter != 0 && (!kEps || p.ncols < (1ll << 27));
+  constexpr int SH = kEps ? 27 : 24;
+
+  for (long long pr0 = wr0; pr0 < wr1; pr0 += RB) {
+    const long long left = wr1 - pr0;
+    const int nr = __builtin_amdgcn_readfirstlane((int)(left < RB ? left : RB));
+
+    // ---- stage the pass's rows into the wave's LDS region (wave private) ----
+    for (int e = lane; e < RB * Q; e += 64) {
+      const int rr = e % RB, q = e / RB;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (rr < nr) v = p.rowPlanes[(long long)q * p.rowNpad + p.row0 + pr0 + rr];
+      rowbuf[wv][rr][q] = v;
+    }
+    const u32 G0 = (MODE == PG_MODE_KNN && canFilter) ? p.knnGuess : 0u;
+    u32 failed = 0;                                         // kNN: rows that lost their optimistic cap (bit = row, all 32 bits in use)
+    u32 resweep = 0;                                        // kNN: 1 in phase 1 (early super-tiles again for the failed rows)
+    int sredo = 0;                                          // kNN: super-tiles [0, sredo) are swept again for them
+    if constexpr (MODE == PG_MODE_KNN) {
+      for (int rr = 0; rr < nr; ++rr) lstbuf[wv][rr][lane] = 0xFFFFFFFFu;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- row operand of the MFMA: lane l holds row l & 31, signature bits 16*(l >> 5) .. +15 ----
+    u32 s31;
+    {
+      uint4 rec[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) rec[q] = rowbuf[wv][lane & 31][q];
+      s31 = pg_sig31(M::fold(rec));
+    }
+    const int pav = __builtin_popcount(s31);                // both lanes of a row hold its popcount
+    pg_v4i A;
+    {
+      const u32 half = (s31 >> (16 * (lane >> 5))) & 0xFFFFu;
+      A[0] = (int)pg_expand_pm1(half);
+      A[1] = (int)pg_expand_pm1(half >> 4);
+      A[2] = (int)pg_expand_pm1(half >> 8);
+      A[3] = (int)pg_expand_pm1(half >> 12);
+    }
+    // the bias byte (k = 31): pa - bound, clamped (a bound beyond 31 + 128 passes everything anyway)
+    auto bias_byte = [&](u32 bound) -> u32 {
+      int b = pav - (int)bound;
+      b = b < -128 ? -128 : b;
+      return ((u32)b & 0xFFu) << 24;
+    };
+    auto set_bound = [&](int row, u32 bound) {              // row, bound wave uniform
+      const u32 nb = ((u32)A[3] & 0x00FFFFFFu) | bias_byte(bound);
+      A[3] = (lane == 32 + row) ? (int)nb : A[3];
+    };
+    auto set_all_bounds = [&](u32 boundv) {                 // boundv: lane r < 32 holds row r's bound
+      const u32 g = (u32)__builtin_amdgcn_ds_bpermute((lane & 31) << 2, (int)boundv);
+      const u32 nb = ((u32)A[3] & 0x00FFFFFFu) | bias_byte(g);
+      A[3] = (lane >= 32) ? (int)nb : A[3];
+    };
+
+    // Per-row state, lane indexed (lane = row in pass), touched with v_readlane / lane selects:
+    //   eps: cntv = matches so far;   knn: thrv = current (k+1)-th smallest key, capv = cap on the bound
+    u32 cntv = 0u, thrv = 0xFFFFFFFFu;
+    u32 capv = G0 ? G0 : 255u;
+    u32 floorv = 0u;                                        // kNN continuation rounds (k > 63)
+    if constexpr (MODE == PG_MODE_KNN) {
+      if (p.floorKeys && lane < nr) floorv = p.floorKeys[pr0 + lane];
+    }
+    const int thrLane = p.knnFirst + p.k - 1;               // last list lane that is still needed
+    set_all_bounds(lane < nr ? (kEps ? p.hi1 : capv) : 0u); // rows past nr: bound 0, nothing passes
+
+    auto publish = [&](int row, u32 thr) {                  // kNN: a row's threshold moved
+      const u32 cp = __builtin_amdgcn_readlane(capv, row);
+      const u32 b = (thr >> 24) + (u32)resweep;             // phase 1: lb <= distance bound may still win a tie
+      set_bound(row, b < cp ? b : cp);
+    };
+    // EPS_SYM: a match (row, col), col > row, also belongs to row `col` (owned by another wave): its
+    // entry goes to the BACK of that row's slot through an atomic counter (pg_compact_kernel sorts it)
+    auto emit_lower = [&](bool on, u32 rowg, u32 col, u32 w) -> u32 {
+      u32 pos = 0xFFFFFFFFu;
+      if constexpr (kSym) {
+        if (on) {
+          pos = atomicAdd(&p.countsLo[col], 1u);
+          if (pos < p.cap) {
+            const long long o = (long long)col * p.cap + (p.cap - 1u - pos);
+            p.slotIdx[o] = (int)rowg;
+            p.slotW[o] = (unsigned char)w;
+          }
+        }
+      }
+      return pos;
+    };
+    // in-place epilogue of the direct form (exact distances of a whole 64-column sub-tile)
+    auto epilogue = [&](u32 d, u32 col, int rr) {
+      if constexpr (kEps) {
+        bool h2 = (d <= p.span) && (col < ncols);
+        if constexpr (kSym) h2 = h2 && col > (u32)(pr0 + rr);
+        const u64 m2 = __builtin_amdgcn_ballot_w64(h2);
+        if (m2) {
+          const u32 cnt = __builtin_amdgcn_readlane(cntv, rr);
+          const u32 pos = cnt + mask_rank(m2);
+          const u32 posb = emit_lower(h2, (u32)(pr0 + rr), col, d + p.lo);
+          if (h2 && pos < p.cap) {
+            const long long o = (pr0 + rr) * (long long)p.cap + pos;
+            p.slotIdx[o] = (int)col;
+            p.slotW[o] = (unsigned char)(d + p.lo);
+            if constexpr (kSym) {
+              if (p.slotAux) p.slotAux[o] = (int)posb;
+            }
+          }
+          cntv = (lane == rr) ? cnt + (u32)__popcll(m2) : cntv;
+        }
+      } else {
+        u32 thr = __builtin_amdgcn_readlane(thrv, rr);
+        const u32 key = (d << 24) | col;
+        bool cand = (key < thr) && (col < ncols);
+        if (p.floorKeys) cand = cand && key > __builtin_amdgcn_readlane(floorv, rr);
+        u64 m = __builtin_amdgcn_ballot_w64(cand);
+        if (m) {
+          u32 lst = lstbuf[wv][rr][lane];
+          do {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const u32 x = __builtin_amdgcn_readlane(key, j);
+            if (x < thr && !(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
+              const u32 prev = wave_shr1(lst, 0u);
+              lst = (lst <= x) ? lst : (prev > x ? prev : x);
+              thr = __builtin_amdgcn_readlane(lst, thrLane);
+            }
+          } while (m);
+          lstbuf[wv][rr][lane] = lst;
+          thrv = (lane == rr) ? thr : thrv;
+          publish(rr, thr);
+        }
+      }
+    };
+
+    // ---- deferred candidates: 64 at a time, one per lane, records gathered (row: LDS, column: L2) ----
+    int qn = 0;                                             // queue fill, wave uniform
+    auto flush = [&]() {
+      const int nbat = qn < 64 ? qn : 64;
+      const u32 e = cq[lane];
+      if constexpr (MODE == PG_MODE_KNN) {
+        const u32 col = e & 0x00FFFFFFu;
+        const u32 erow = (e >> 24) & 31u;
+        const bool act = lane < nbat && col < ncols;
+        u32 key = 0xFFFFFFFFu, thr = 0u;
+        if (act) {
+          uint4 cr[Q], rw[Q];                               // all gathers in flight at once
+#pragma unroll
+          for (int q = 0; q < Q; ++q) cr[q] = colp[(long long)q * p.colNpad + col];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) rw[q] = rowbuf[wv][erow][q];
+          const u32 d = M::dist(rw, cr, 0u);
+          key = (d << 24) | col;
+          thr = lstbuf[wv][erow][thrLane];
+        }
+        const bool cand = act && key < thr;
+        u64 m = __builtin_amdgcn_ballot_w64(cand);
+        while (m) {
+          const int j = __builtin_ctzll(m);
+          m &= m - 1;
+          const int row = (int)__builtin_amdgcn_readlane(erow, j);
+          const u32 x = __builtin_amdgcn_readlane(key, j);
+          if (p.floorKeys && x <= __builtin_amdgcn_readlane(floorv, row)) continue;   // continuation round
+          u32 lst = lstbuf[wv][row][lane];
+          if (x < __builtin_amdgcn_readlane(lst, thrLane) && !(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
+            const u32 prev = wave_shr1(lst, 0u);
+            lst = (lst <= x) ? lst : (prev > x ? prev : x);
+            lstbuf[wv][row][lane] = lst;
+            const u32 nthr = __builtin_amdgcn_readlane(lst, thrLane);
+            thrv = (lane == row) ? nthr : thrv;
+            publish(row, nthr);
+          }
+        }
+      } else {
+        const u32 col = e & 0x07FFFFFFu;
+        const u32 erow = e >> 27;
+        const bool act = lane < nbat && col < ncols;
+        u32 d = 0xFFFFFFFFu;
+        if (act) {
+          uint4 cr[Q], rw[Q];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) cr[q] = colp[(long long)q * p.colNpad + col];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) rw[q] = rowbuf[wv][erow][q];
+          d = M::dist(rw, cr, bias);
+        }
+        bool match = act && d <= p.span;
+        if constexpr (kSym) match = match && col > (u32)pr0 + erow;
+        const u32 posb = emit_lower(match, (u32)pr0 + erow, col, d + p.lo);
+        u64 m = __builtin_amdgcn_ballot_w64(match);
+        while (m) {                                          // one turn per row present in the batch
+          const u32 row = __builtin_amdgcn_readlane(erow, __builtin_ctzll(m));
+          const bool mine = match && erow == row;
+          const u64 same = __builtin_amdgcn_ballot_w64(mine);
+          const u32 cnt = __builtin_amdgcn_readlane(cntv, (int)row);
+          const u32 pos = cnt + mask_rank(same);
+          if (mine && pos < p.cap) {
+            const long long o = (pr0 + row) * (long long)p.cap + pos;
+            p.slotIdx[o] = (int)col;
+            p.slotW[o] = (unsigned char)(d + p.lo);
+            if constexpr (kSym) {
+              if (p.slotAux) p.slotAux[o] = (int)posb;
+            }
+          }
+          cntv = (lane == (int)row) ? cnt + (u32)__popcll(same) : cntv;
+          m &= ~same;
+        }
+      }
+      if (qn > 64) {                                         // keep the tail (at most 63 entries), in order
+        const u32 tail = cq[64 + lane];
+        cq[lane] = tail;
+      }
+      qn -= nbat;
+    };
+
+    // ---- filtered form: one super-tile = four MFMA tiles.  The hot path only TESTS: per tile one MFMA
+    // and the OR of its 16 result registers, per super-tile one sign test + branch; two accumulator
+    // sets alternate so that a result is reduced while the next MFMA runs, and the consumed
+    // fragment register is refilled at once with the next super-tile's (four loads in flight).
+    // A tile that holds candidates is evaluated AGAIN in the slow path (fragment re-read from L2,
+    // one more MFMA): that keeps a single copy of the queueing code and no result registers live
+    // across it. ----
+    int wpush = 0;                                          // candidates queued in the current window
+    const pg_v16i zero16 = {0};
+    auto extract_tile = [&](int tile) {
+      const pg_v4i b = colsig[(long long)tile * 64 + lane];
+      const pg_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, b, zero16, 0, 0, 0);
+      const u32 ecol = (u32)(tile * 32 + (lane & 31));
+      const u32 erow0 = 4u * (u32)(lane >> 5);
+      u32 done = 0;                                         // result registers already queued
+      do {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (((done >> r) & 1u) == 0 && qn < 64) {
+            done |= 1u << r;
+            const bool hit = d[r] < 0;
+            const u64 mb = __builtin_amdgcn_ballot_w64(hit);
+            if (mb) {
+              // C/D layout of the 32x32 MFMA: register r, lane l -> row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31
+              const u32 row = (u32)((r & 3) + 8 * (r >> 2)) + erow0;
+              if (hit) cq[qn + mask_rank(mb)] = (row << SH) | ecol;
+              const int np = __builtin_popcount((u32)mb) + __builtin_popcount((u32)(mb >> 32));
+              qn += np;
+              wpush += np;
+            }
+          }
+        }
+        if (qn >= 64) flush();
+      } while (done != 0xFFFFu);
+    };
+    pg_v4i ring[4];
+    int ringS = -1;                                         // super-tile whose fragments the ring holds
+    auto sweep_mfma = [&](int S, int Snext) {
+      if (ringS != S) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ring[i] = colsig[(long long)(S * 4 + i) * 64 + lane];
+      }
+      const pg_v4i *nx = colsig + (long long)Snext * 4 * 64 + lane;
+      pg_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, ring[0], zero16, 0, 0, 0);
+      ring[0] = nx[0];
+      pg_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, ring[1], zero16, 0, 0, 0);
+      ring[1] = nx[64];
+      const int a0 = pg_or16(d0);
+      d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, ring[2], zero16, 0, 0, 0);
+      ring[2] = nx[128];
+      const int a1 = pg_or16(d1);
+      d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, ring[3], zero16, 0, 0, 0);
+      ring[3] = nx[192];
+      const int a2 = pg_or16(d0);
+      const int a3 = pg_or16(d1);
+      ringS = Snext;
+      if (__builtin_amdgcn_ballot_w64((a0 | a1 | a2 | a3) < 0)) {
+        u32 tm = (__builtin_amdgcn_ballot_w64(a0 < 0) ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(a1 < 0) ? 2u : 0u) |
+                 (__builtin_amdgcn_ballot_w64(a2 < 0) ? 4u : 0u) | (__builtin_amdgcn_ballot_w64(a3 < 0) ? 8u : 0u);
+        while (tm) {                                        // ascending tiles: queue order = column order per row
+          const int i = __builtin_ctz(tm);
+          tm &= tm - 1;
+          extract_tile(S * 4 + i);
+        }
+      }
+    };
+
+    // ---- direct form of one super-tile: whole column records in registers, every exact distance ----
+    auto row_direct = [&](const uint4 (&c)[C][Q], int rr, u32 col0) {
+      uint4 r[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) r[q] = rows[rr * Q + q];
+      u32 d[C];
+#pragma unroll
+      for (int b = 0; b < C; ++b) d[b] = M::dist(r, c[b], bias);
+      u32 dmin = d[0];
+#pragma unroll
+      for (int b = 1; b < C; ++b) dmin = dmin < d[b] ? dmin : d[b];
+      const u32 bound = kEps ? p.span + 1u : (__builtin_amdgcn_readlane(thrv, rr) >> 24) + (u32)resweep;
+      if (__builtin_amdgcn_ballot_w64(dmin < bound)) {
+#pragma unroll
+        for (int b = 0; b < C; ++b) epilogue(d[b], col0 + b * 64, rr);
+      }
+    };
+    auto sweep_direct = [&](int S) {
+#pragma unroll 1
+      for (int sub = 0; sub < PG_MM_ST / (64 * C); ++sub) {
+        const u32 col0 = (u32)(S * PG_MM_ST + sub * 64 * C) + lane;
+        uint4 c[C][Q];
+#pragma unroll
+        for (int b = 0; b < C; ++b)
+#pragma unroll
+          for (int q = 0; q < Q; ++q) c[b][q] = colp[(long long)q * p.colNpad + col0 + b * 64];
+        for (int rr = 0; rr < nr; ++rr) row_direct(c, rr, col0);
+      }
+    };
+
+    // Adaptive choice per window of 8 super-tiles: when more than 1/5 of the window's pairs were
+    // queued, the exact evaluation of gathered candidates costs more than computing every distance
+    // of the tile in place; 120 super-tiles then run direct before the filter is probed again.
+    int win_st = 0, direct_left = 0;
+    auto sweep = [&](int S, int Snext) {
+      if (canFilter && (resweep || p.filter == 2 || direct_left == 0)) {
+        sweep_mfma(S, Snext);
+        if (++win_st == 8) {
+          if (p.filter == 1 && !resweep && wpush * 5 > nr * 8 * PG_MM_ST) direct_left = 120;
+          win_st = 0;
+          wpush = 0;
+        }
+        return;
+      }
+      if (direct_left > 0) --direct_left;
+      while (qn > 0) flush();                               // in-place results must come after queued ones
+      sweep_direct(S);
+    };
+
+    // kNN checkpoints (first super-tile after them): after 1/32 of the sweep a row without any near
+    // column yet is taken to be unclustered and loses the cap; after 1/8 every row whose list is
+    // not settled below G0 does.  Phase 1 covers the larger range in use.
+    auto checkpoint = [&](int snext) {
+      if constexpr (MODE == PG_MODE_KNN) {
+        const int sw1 = (nst + 31) >> 5, sw2 = (nst + 7) >> 3;
+        if (G0 && !resweep && (snext == sw1 || snext == sw2)) {
+          while (qn > 0) flush();
+          const bool mine = lane < nr && !((failed >> (lane & 31)) & 1);
+          u32 dref = thrv >> 24;                             // open lists read 255
+          if (snext != sw2) dref = mine ? lstbuf[wv][lane][p.knnFirst] >> 24 : 0u;
+          const bool late = mine && dref >= G0;
+          const u32 now = (u32)__builtin_amdgcn_ballot_w64(late);   // rows < 32
+          if (now) {
+            failed |= now;
+            sredo = snext;
+            if (late) capv = 255u;
+            const u32 b = thrv >> 24;
+            set_all_bounds(lane < nr ? (b < capv ? b : capv) : 0u);
+          }
+        }
+      }
+    };
+
+    int send = nst;
+    const int sbeg = kSym ? (int)(pr0 / PG_MM_ST) : 0;     // EPS_SYM: from the super-tile that holds the pass's first row
+    for (;;) {
+      for (int S = sbeg; S < send; ++S) {
+        sweep(S, S + 1 < send ? S + 1 : S);
+        checkpoint(S + 1);
+      }
+      while (qn > 0) flush();
+      if constexpr (MODE == PG_MODE_KNN) {
+        if (!failed || resweep) break;
+        // phase 1: the rows that lost their cap see super-tiles [0, sredo) again; the others are frozen
+        resweep = 1;
+        set_all_bounds((lane < nr && ((failed >> (lane & 31)) & 1)) ? (thrv >> 24) + 1u : 0u);
+        send = sredo;
+        win_st = 0; wpush = 0; direct_left = 0;
+        ringS = -1;
+      } else {
+        break;
+      }
+    }
+
+    // ---- per-row results of this pass ----
+    if constexpr (kEps) {
+      if (lane < nr) p.counts[pr0 + lane] = cntv;
+    } else {
+      for (int rr = 0; rr < nr; ++rr) {
+        const u32 key = lstbuf[wv][rr][lane];
+        if (lane >= p.knnFirst && lane < p.knnFirst + p.k) {
+          const long long o = (pr0 + rr) * (long long)p.k + (lane - p.knnFirst);
+          p.knnIdx[o] = (key == 0xFFFFFFFFu) ? -1 : (int)(key & 0x00FFFFFFu);
+          p.knnDist[o] = (unsigned char)(key >> 24);
+        }
+        if (p.lastKeys && lane == thrLane) p.lastKeys[pr0 + rr] = key;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+

@@ -2,6 +2,7 @@
 // Byte alphabets (8 planes) are instantiated up to G = 4 (L <= 128); beyond that the record no
 // longer fits two register sets and callers take the generic path.
 #include "pg_nsq.h"
+#include "pg_mm.h"
 
 #ifndef PG_G
 #error "compile with -DPG_G=<1..8>"
@@ -58,6 +59,23 @@ int PG_CAT(pg_launch_nsq_g, PG_G)(int mode, int bits, const NsqParams &p, int gr
     return bits == 5 ? launch_nsq<5, PG_MODE_EPS_SYM>(p, grid, s) : launch_nsq<8, PG_MODE_EPS_SYM>(p, grid, s);
   if (mode == PG_MODE_EPS) return bits == 5 ? launch_nsq<5, PG_MODE_EPS>(p, grid, s) : launch_nsq<8, PG_MODE_EPS>(p, grid, s);
   return bits == 5 ? launch_nsq<5, PG_MODE_KNN>(p, grid, s) : launch_nsq<8, PG_MODE_KNN>(p, grid, s);
+}
+
+template <int B, int MODE>
+static int launch_mm(const NsqParams &p, int grid, hipStream_t s) {
+  if constexpr (Cols<B>::kBuilt) {
+    pg_mm_kernel<HammingMetric<PG_G, B>, MODE><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+    return (int)hipGetLastError();
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+}
+
+int PG_CAT(pg_launch_mm_g, PG_G)(int mode, int bits, const NsqParams &p, int grid, hipStream_t s) {
+  if (mode == PG_MODE_EPS_SYM)
+    return bits == 5 ? launch_mm<5, PG_MODE_EPS_SYM>(p, grid, s) : launch_mm<8, PG_MODE_EPS_SYM>(p, grid, s);
+  if (mode == PG_MODE_EPS) return bits == 5 ? launch_mm<5, PG_MODE_EPS>(p, grid, s) : launch_mm<8, PG_MODE_EPS>(p, grid, s);
+  return bits == 5 ? launch_mm<5, PG_MODE_KNN>(p, grid, s) : launch_mm<8, PG_MODE_KNN>(p, grid, s);
 }
 
 template <int B>

@@ -33,9 +33,8 @@ int main(int argc, char **argv) {
 
   // ---- device side: tokens -> planes
   const int64_t npad = pg_npad(n);
-  const int q = pg_nchunks(l, PG_BITS_5);
   uint8_t *d_tok = dmalloc<uint8_t>((size_t)n * l);
-  uint8_t *d_planes = dmalloc<uint8_t>((size_t)q * npad * 16);
+  uint8_t *d_planes = dmalloc<uint8_t>((size_t)pg_planes_bytes(n, l, PG_BITS_5));
   uint32_t *d_flag = dmalloc<uint32_t>(1);
   HIP(hipMemcpy(d_tok, tok.data(), (size_t)n * l, hipMemcpyHostToDevice));
   PG(pg_pack_planes(d_tok, 1, n, l, l, nullptr, PG_BITS_5, d_planes, npad, d_flag, nullptr));
