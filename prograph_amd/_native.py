@@ -145,8 +145,8 @@ def nchunks(l, bits):
 
 
 def planes_bytes(n, l, bits):
-    """Chunk arrays + the 32-byte-per-sequence signature section (MFMA column operand)."""
-    return (nchunks(l, bits) * 16 + 32) * npad(n)
+    """Chunk arrays + four signature sections of 32 bytes per sequence (MFMA column operands)."""
+    return (nchunks(l, bits) * 16 + 32 * 4) * npad(n)
 
 
 class Planes:

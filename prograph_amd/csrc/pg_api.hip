@@ -67,7 +67,7 @@ int pg_device_info(int *cus, int *wave, char *arch, int arch_len) {
 int64_t pg_npad(int64_t n) { return n <= 0 ? 256 : ((n + 255) / 256) * 256; }
 int pg_ngroups(int l) { return l <= 0 ? 1 : (l + 31) / 32; }
 int pg_nchunks(int l, int bits) { return (pg_ngroups(l) * bits + 3) / 4; }
-int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunks(l, bits) * 16 + 32) * pg_npad(n); }
+int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunks(l, bits) * 16 + 32 * PG_MM_NP) * pg_npad(n); }
 
 }  // extern "C"
 
@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
   if (s >= npad) return;
   const T *row = nullptr;
   if (s < n) row = src + (rows ? rows[s] : s) * ld;
-  u32 bad = 0, sig = 0;
+  u32 bad = 0, sig[PG_MM_NP];
+#pragma unroll
+  for (int p = 0; p < PG_MM_NP; ++p) sig[p] = 0;
   for (int g = 0; g < ng; ++g) {
     u32 pl[B];
 #pragma unroll
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
         }
       }
     }
-    sig ^= pl[0];                             // filter signature: XOR fold of the plane-0 words
+#pragma unroll
+    for (int p = 0; p < PG_MM_NP; ++p) sig[p] ^= pl[p];   // filter signatures: XOR fold of each plane's words
 #pragma unroll
     for (int p = 0; p < B; ++p) {
       const int w = p * ng + g;               // plane-major record order
@@ -106,13 +109,15 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
     }
   }
   for (int w = ng * B; w < nq * 4; ++w) planes[((long long)(w >> 2) * npad + s) * 4 + (w & 3)] = 0;
-  // Signature section (after the nq chunk arrays): the column operand of the stage-1 MFMA
-  // (pg_mm.h), one byte per signature bit, per 32 sequences one 1 KiB block in fragment order:
-  // uint4 [tile][h * 32 + c] = bytes k = 16h .. 16h+15 of sequence 32 * tile + c; byte 31 is the
-  // constant 1 that multiplies the row's bias (0 for padding sequences: they never pass).
-  {
-    const u32 s31 = pg_sig31(sig);
-    uint4 *e = reinterpret_cast<uint4 *>(planes + (long long)nq * npad * 4) + (s >> 5) * 64 + (s & 31);
+  // Signature sections (after the nq chunk arrays, one per bit plane 0..PG_MM_NP-1, 32 * npad bytes
+  // each): the column operands of the filter MFMAs (pg_mm.h), one byte per signature bit, per 32
+  // sequences one 1 KiB block in fragment order: uint4 [tile][h * 32 + c] = bytes k = 16h .. 16h+15
+  // of sequence 32 * tile + c; byte 31 is the constant 1 that multiplies the row's bias (0 for
+  // padding sequences: they never pass).
+#pragma unroll
+  for (int p = 0; p < PG_MM_NP; ++p) {
+    const u32 s31 = pg_sig31(sig[p]);
+    uint4 *e = reinterpret_cast<uint4 *>(planes + (long long)nq * npad * 4) + (long long)p * npad * 2 + (s >> 5) * 64 + (s & 31);
     e[0] = make_uint4(pg_spread4(s31), pg_spread4(s31 >> 4), pg_spread4(s31 >> 8), pg_spread4(s31 >> 12));
     e[32] = make_uint4(pg_spread4(s31 >> 16), pg_spread4(s31 >> 20), pg_spread4(s31 >> 24),
                        pg_spread4(s31 >> 28) | (row ? 0x01000000u : 0u));
@@ -479,6 +484,15 @@ static bool use_mm_engine(int64_t nrows) {
   const long long thr = getenv("PG_ENGINE_MIN_ROWS") ? atoll(getenv("PG_ENGINE_MIN_ROWS")) : 65536;
   return nrows >= thr;
 }
+#ifdef PG_MM_STATS
+static unsigned long long *g_stats = nullptr;
+extern "C" int pg_debug_stats(unsigned long long *out12, int reset) {   // debug builds only (tools/mm_stats.py)
+  if (!g_stats) { if (hipMalloc(&g_stats, 16 * 8) != hipSuccess) return -1; hipMemset(g_stats, 0, 16 * 8); }
+  if (out12) { hipDeviceSynchronize(); hipMemcpy(out12, g_stats, 12 * 8, hipMemcpyDeviceToHost); }
+  if (reset) hipMemset(g_stats, 0, 16 * 8);
+  return 0;
+}
+#endif
 static const nsq_fn kMm[8] = {pg_launch_mm_g1, pg_launch_mm_g2, pg_launch_mm_g3, pg_launch_mm_g4,
                               pg_launch_mm_g5, pg_launch_mm_g6, pg_launch_mm_g7, pg_launch_mm_g8};
 // one pass of 32 rows per wave (PG_ROWS_PER_WAVE: whole passes)
@@ -486,6 +500,14 @@ static void plan_mm(int64_t nrows, NsqParams *p, int *grid) {
   long long rpw = PG_MM_RB;
   if (const char *e = getenv("PG_ROWS_PER_WAVE")) { if (atoi(e) > 0) rpw = (atoi(e) + PG_MM_RB - 1) / PG_MM_RB * PG_MM_RB; }
   p->rowsPerWave = (int)rpw; p->rowsPerPass = PG_MM_RB;
+  p->mmDenseL1 = getenv("PG_MM_L1") ? atoi(getenv("PG_MM_L1")) : PG_MM_DENSE_L1;
+  p->mmDenseL2 = getenv("PG_MM_L2") ? atoi(getenv("PG_MM_L2")) : PG_MM_DENSE_L2;
+  p->mmDirectRun = getenv("PG_MM_RUN") ? atoi(getenv("PG_MM_RUN")) : PG_MM_DIRECT_RUN;
+  if (p->mmDirectRun < 1) p->mmDirectRun = 1;
+#ifdef PG_MM_STATS
+  if (!g_stats) pg_debug_stats(nullptr, 1);
+  p->stats = g_stats;
+#endif
   const long long waves = (nrows + rpw - 1) / rpw;
   *grid = (int)((waves + PG_WG_WAVES - 1) / PG_WG_WAVES);
 }
@@ -606,7 +628,8 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   if (ncols > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_knn_hamming: ncols exceeds 2^24");
   p.k = k; p.knnFirst = first; p.floorKeys = floor_keys; p.lastKeys = last_keys;
   // optimistic stage-1 cap (pg_nsq.h): 8 = half of what unrelated sequences show in the plane-0 bound
-  p.knnGuess = getenv("PG_KNN_GUESS") ? (u32)atoi(getenv("PG_KNN_GUESS")) : 8u;
+  // (pg_mm.h: 6 - a tile of 1024 pairs is examined as soon as one pair passes, so false candidates cost more there)
+  p.knnGuess = getenv("PG_KNN_GUESS") ? (u32)atoi(getenv("PG_KNN_GUESS")) : (use_mm_engine(nrows) ? 6u : 8u);
   if (p.filter == 0) p.knnGuess = 0;                       // no stage 1, nothing to cap
   p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;

@@ -145,6 +145,16 @@ struct HammingMetric {
     for (int g = 1; g < G; ++g) s ^= w[g];
     return s;
   }
+  // XOR fold of plane `pl`'s words over all groups (the signature of that plane; pl = 0: fold())
+  static __device__ __forceinline__ u32 fold_plane(const uint4 (&rec)[Q], int pl) {
+    u32 w[4 * Q];
+    unpack<Q>(rec, w);
+    if (pl >= B) return 0u;
+    u32 s = w[pl * G];
+#pragma unroll
+    for (int g = 1; g < G; ++g) s ^= w[pl * G + g];
+    return s;
+  }
   static __device__ __forceinline__ u32 lb_prep(const uint4 &r0, const uint4 &c0) { return r0.x ^ c0.x; }
   static __device__ __forceinline__ u32 lb_finish(u32 x, const uint4 &r0, const uint4 &c0, u32 seed) {
     constexpr int GL = G < PG_LB_GROUPS ? G : PG_LB_GROUPS;
@@ -206,8 +216,10 @@ struct NsqParams {
   long long rowNpad, row0, nrows;
   const uint4 *colPlanes;
   long long colNpad, ncols;
+  unsigned long long *stats;   // debug builds (-DPG_MM_STATS): event counters of pg_mm_kernel, else unused
   const uint4 *colSig;  // signature section of the column operand: MFMA B fragments, 1 KiB per 32 columns (pg_mm.h)
   int rowsPerWave, rowsPerPass;
+  int mmDenseL1, mmDenseL2, mmDirectRun;   // pg_mm.h: density rules of the filter hierarchy
   int filter;   // 1 = plane-0 lower-bound filter allowed (adaptive per tile), 0 = always direct
   u32 knnGuess; // kNN: optimistic cap on the stage-1 bound until a row's list is full (0 = off), see pg_nsq.h
   // eps

@@ -28,9 +28,14 @@
 //   * candidates (D < 0) are queued as (row, column) in LDS and evaluated exactly 64 at a time, one
 //     per lane, with gathered records - as in pg_nsq.h, but now for every candidate (the column
 //     records are no longer in registers);
-//   * dense data (most pairs pass stage 1) switches a wave to the DIRECT form for a while: whole
-//     column records in registers, every exact distance computed (the form pg_nsq.h falls back
-//     to as well); the decision is per wave and per window of tiles.
+//   * DENSE data (mutant libraries: most pairs pass the plane-0 bound) climbs a hierarchy per
+//     super-tile of 128 columns.  Level 1 = the plane-0 signature above.  When more than 3/4 of a
+//     super-tile's (column, 16-row) lane slots hold a level-1 candidate, level 2 evaluates the
+//     signatures of bit planes 0..3 (one MFMA each, sign bits AND-ed: a pair can only be within the
+//     bound if it is within it in every plane; that leaves little more than the true matches).  When level 2 is dense too (the true matches themselves are dense: loose eps, or
+//     kNN rows whose lists are still open) the wave runs the DIRECT form for 8 super-tiles: whole
+//     column records in registers, every exact distance computed in place (the form pg_nsq.h
+//     falls back to as well), then probes again.
 // kNN keeps the optimistic cap / checkpoint / second-phase scheme of pg_nsq.h (exactness argument
 // there and in DESIGN.md §4.1); only the representation of the bound changed.
 #pragma once
@@ -42,6 +47,12 @@ typedef int pg_v16i __attribute__((ext_vector_type(16)));
 #define PG_MM_RB 32          // rows per pass = M of the MFMA tile
 #define PG_MM_QCAP 128       // candidate queue entries per wave: < 64 before a push, <= 64 per push
 #define PG_MM_ST 128         // columns per super-tile: 4 MFMA tiles = one direct-form tile (C = 2)
+#define PG_MM_NP 4           // bit planes with a signature section: level 2 of the filter uses planes 0..3 (each costs 4 VGPRs
+                             // of row operand; plane 4 of the 5-bit alphabet only separates tokens 16..20 from the rest)
+// defaults of the density rules (NsqParams carries them: PG_MM_L1 / PG_MM_L2 / PG_MM_RUN override for experiments)
+#define PG_MM_DENSE_L1 96    // of 256 lane slots per super-tile with a level-1 candidate: go to level 2
+#define PG_MM_DENSE_L2 48    // of 64 lane slots of the first tile still occupied at level 2: run direct
+#define PG_MM_DIRECT_RUN 8   // super-tiles of direct form before the filter is probed again
 
 static_assert(PG_MM_QCAP >= 63 + 64, "a register push adds up to 64 candidates to a queue holding up to 63");
 static_assert(PG_QCAP >= 63 + 4 * 2 * PG_PUSH_MAX, "pg_nsq.h kNN queue: a group pushes up to 4 rows x 2 columns x PG_PUSH_MAX");
@@ -72,6 +83,7 @@ template <class M, int MODE>
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
   constexpr int C = Q <= 4 ? 2 : 1;                        // direct form: columns per lane
+  constexpr int NP = PG_MM_NP;
   constexpr bool kEps = MODE != PG_MODE_KNN;
   constexpr bool kSym = MODE == PG_MODE_EPS_SYM;
   constexpr int RB = PG_MM_RB;
@@ -87,6 +99,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
   const long long wr1 = (wr0 + p.rowsPerWave < p.nrows) ? wr0 + p.rowsPerWave : p.nrows;
   const uint4 *__restrict__ colp = p.colPlanes;
   const pg_v4i *__restrict__ colsig = reinterpret_cast<const pg_v4i *>(p.colSig);
+  const long long sigStride = p.colNpad * 2;               // uint4 per plane section (32 bytes per sequence)
   const u32 ncols = (u32)p.ncols;
   const int nst = (int)((p.ncols + PG_MM_ST - 1) / PG_MM_ST);   // super-tiles of 128 columns
   const uint4 *rows = &rowbuf[wv][0][0] + opaque_zero();   // broadcast reads, kept "divergent"
@@ -96,8 +109,16 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
   const bool canFilter = p.filter != 0 && (!kEps || p.ncols < (1ll << 27));
   constexpr int SH = kEps ? 27 : 24;
 
+#ifdef PG_MM_STATS
+  u32 st[12] = {0};   // 0 L1 super-tiles, 1 with candidates, 2 escalated to L2, 3 L2-dense (direct runs), 4 direct super-tiles,
+                      // 5 tiles queued from, 6 candidates queued, 7 flushes, 8 insertions / eps matches, 9 resweep super-tiles, 10 passes
+#define PG_ST(i, n) st[i] += (u32)(n)
+#else
+#define PG_ST(i, n)
+#endif
   for (long long pr0 = wr0; pr0 < wr1; pr0 += RB) {
     const long long left = wr1 - pr0;
+    PG_ST(10, 1);
     const int nr = __builtin_amdgcn_readfirstlane((int)(left < RB ? left : RB));
 
     // ---- stage the pass's rows into the wave's LDS region (wave private) ----
@@ -118,37 +139,51 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- row operand of the MFMA: lane l holds row l & 31, signature bits 16*(l >> 5) .. +15 ----
-    u32 s31;
+    // ---- row operands of the MFMAs, one per bit plane: lane l holds row l & 31, signature bits
+    // 16*(l >> 5) .. +15 of that plane; papack = the row's signature popcounts, 6 bits per plane ----
+    pg_v4i A[NP];
+    u32 papack = 0;
     {
       uint4 rec[Q];
 #pragma unroll
       for (int q = 0; q < Q; ++q) rec[q] = rowbuf[wv][lane & 31][q];
-      s31 = pg_sig31(M::fold(rec));
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        const u32 s31 = pg_sig31(M::fold_plane(rec, pl));
+        papack |= (u32)__builtin_popcount(s31) << (6 * pl);
+        const u32 half = (s31 >> (16 * (lane >> 5))) & 0xFFFFu;
+        A[pl][0] = (int)pg_expand_pm1(half);
+        A[pl][1] = (int)pg_expand_pm1(half >> 4);
+        A[pl][2] = (int)pg_expand_pm1(half >> 8);
+        A[pl][3] = (int)pg_expand_pm1(half >> 12);
+      }
     }
-    const int pav = __builtin_popcount(s31);                // both lanes of a row hold its popcount
-    pg_v4i A;
-    {
-      const u32 half = (s31 >> (16 * (lane >> 5))) & 0xFFFFu;
-      A[0] = (int)pg_expand_pm1(half);
-      A[1] = (int)pg_expand_pm1(half >> 4);
-      A[2] = (int)pg_expand_pm1(half >> 8);
-      A[3] = (int)pg_expand_pm1(half >> 12);
-    }
-    // the bias byte (k = 31): pa - bound, clamped (a bound beyond 31 + 128 passes everything anyway)
-    auto bias_byte = [&](u32 bound) -> u32 {
-      int b = pav - (int)bound;
+    // A row's bound: lanes 32.. hold it in boundv (authoritative) and, as pa - bound clamped to int8,
+    // in the top byte of A[0][3] (k = 31).  A bound beyond pa + 128 passes everything either way.
+    u32 boundv = 0;
+    auto bias_byte = [&](int pl, u32 bound) -> u32 {
+      int b = (int)((papack >> (6 * pl)) & 63u) - (int)bound;
       b = b < -128 ? -128 : b;
       return ((u32)b & 0xFFu) << 24;
     };
     auto set_bound = [&](int row, u32 bound) {              // row, bound wave uniform
-      const u32 nb = ((u32)A[3] & 0x00FFFFFFu) | bias_byte(bound);
-      A[3] = (lane == 32 + row) ? (int)nb : A[3];
+      const u32 nb = ((u32)A[0][3] & 0x00FFFFFFu) | bias_byte(0, bound);
+      const bool me = lane == 32 + row;
+      A[0][3] = me ? (int)nb : A[0][3];
+      boundv = me ? bound : boundv;
     };
-    auto set_all_bounds = [&](u32 boundv) {                 // boundv: lane r < 32 holds row r's bound
-      const u32 g = (u32)__builtin_amdgcn_ds_bpermute((lane & 31) << 2, (int)boundv);
-      const u32 nb = ((u32)A[3] & 0x00FFFFFFu) | bias_byte(g);
-      A[3] = (lane >= 32) ? (int)nb : A[3];
+    auto set_all_bounds = [&](u32 bv) {                     // bv: lane r < 32 holds row r's bound
+      const u32 g = (u32)__builtin_amdgcn_ds_bpermute((lane & 31) << 2, (int)bv);
+      const u32 nb = ((u32)A[0][3] & 0x00FFFFFFu) | bias_byte(0, g);
+      A[0][3] = (lane >= 32) ? (int)nb : A[0][3];
+      boundv = g;
+    };
+    auto refresh_level2 = [&]() {                           // the other planes follow boundv only when level 2 runs
+#pragma unroll
+      for (int pl = 1; pl < NP; ++pl) {
+        const u32 nb = ((u32)A[pl][3] & 0x00FFFFFFu) | bias_byte(pl, boundv);
+        A[pl][3] = (lane >= 32) ? (int)nb : A[pl][3];
+      }
     };
 
     // Per-row state, lane indexed (lane = row in pass), touched with v_readlane / lane selects:
@@ -164,7 +199,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
 
     auto publish = [&](int row, u32 thr) {                  // kNN: a row's threshold moved
       const u32 cp = __builtin_amdgcn_readlane(capv, row);
-      const u32 b = (thr >> 24) + (u32)resweep;             // phase 1: lb <= distance bound may still win a tie
+      const u32 b = (thr >> 24) + resweep;                  // phase 1: lb <= distance bound may still win a tie
       set_bound(row, b < cp ? b : cp);
     };
     // EPS_SYM: a match (row, col), col > row, also belongs to row `col` (owned by another wave): its
@@ -232,6 +267,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
     int qn = 0;                                             // queue fill, wave uniform
     auto flush = [&]() {
       const int nbat = qn < 64 ? qn : 64;
+      PG_ST(7, 1);
       const u32 e = cq[lane];
       if constexpr (MODE == PG_MODE_KNN) {
         const u32 col = e & 0x00FFFFFFu;
@@ -261,6 +297,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
             const u32 prev = wave_shr1(lst, 0u);
             lst = (lst <= x) ? lst : (prev > x ? prev : x);
             lstbuf[wv][row][lane] = lst;
+            PG_ST(8, 1);
             const u32 nthr = __builtin_amdgcn_readlane(lst, thrLane);
             thrv = (lane == row) ? nthr : thrv;
             publish(row, nthr);
@@ -298,6 +335,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
             }
           }
           cntv = (lane == (int)row) ? cnt + (u32)__popcll(same) : cntv;
+          PG_ST(8, __popcll(same));
           m &= ~same;
         }
       }
@@ -308,20 +346,16 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
       qn -= nbat;
     };
 
-    // ---- filtered form: one super-tile = four MFMA tiles.  The hot path only TESTS: per tile one MFMA
-    // and the OR of its 16 result registers, per super-tile one sign test + branch; two accumulator
-    // sets alternate so that a result is reduced while the next MFMA runs, and the consumed
-    // fragment register is refilled at once with the next super-tile's (four loads in flight).
-    // A tile that holds candidates is evaluated AGAIN in the slow path (fragment re-read from L2,
-    // one more MFMA): that keeps a single copy of the queueing code and no result registers live
-    // across it. ----
-    int wpush = 0;                                          // candidates queued in the current window
+    // ---- filtered form.  Hot path per super-tile: four level-1 MFMAs, the OR of each result, ONE
+    // sign test + branch; a consumed fragment register is refilled at once with the next super-tile's
+    // (four loads in flight).  A tile that holds candidates is evaluated AGAIN in the slow path
+    // (fragment re-read from L2): one copy of the queueing code, no result registers live across it. ----
     const pg_v16i zero16 = {0};
-    auto extract_tile = [&](int tile) {
-      const pg_v4i b = colsig[(long long)tile * 64 + lane];
-      const pg_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, b, zero16, 0, 0, 0);
-      const u32 ecol = (u32)(tile * 32 + (lane & 31));
-      const u32 erow0 = 4u * (u32)(lane >> 5);
+    // queue the candidates (negative entries) of one tile's result registers
+    // C/D layout of the 32x32 MFMA: register r, lane l -> row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31
+    auto queue_from = [&](const pg_v16i &d, int tile) {
+      PG_ST(5, 1);
+      const u32 ebase = ((4u * (u32)(lane >> 5)) << SH) | (u32)(tile * 32 + (lane & 31));
       u32 done = 0;                                         // result registers already queued
       do {
 #pragma unroll
@@ -331,12 +365,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
             const bool hit = d[r] < 0;
             const u64 mb = __builtin_amdgcn_ballot_w64(hit);
             if (mb) {
-              // C/D layout of the 32x32 MFMA: register r, lane l -> row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31
-              const u32 row = (u32)((r & 3) + 8 * (r >> 2)) + erow0;
-              if (hit) cq[qn + mask_rank(mb)] = (row << SH) | ecol;
-              const int np = __builtin_popcount((u32)mb) + __builtin_popcount((u32)(mb >> 32));
-              qn += np;
-              wpush += np;
+              if (hit) cq[qn + mask_rank(mb)] = ebase + ((u32)((r & 3) + 8 * (r >> 2)) << SH);
+              qn += __builtin_popcount((u32)mb) + __builtin_popcount((u32)(mb >> 32));
+              PG_ST(6, __popcll(mb));
             }
           }
         }
@@ -345,83 +376,108 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
     };
     pg_v4i ring[4];
     int ringS = -1;                                         // super-tile whose fragments the ring holds
-    auto sweep_mfma = [&](int S, int Snext) {
+    // level 1 of one super-tile; returns true when level 1 is not selective here (nothing was queued)
+    auto sweep_mfma = [&](int S, int Snext) -> bool {
       if (ringS != S) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) ring[i] = colsig[(long long)(S * 4 + i) * 64 + lane];
       }
       const pg_v4i *nx = colsig + (long long)Snext * 4 * 64 + lane;
-      pg_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, ring[0], zero16, 0, 0, 0);
+      pg_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], ring[0], zero16, 0, 0, 0);
       ring[0] = nx[0];
-      pg_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, ring[1], zero16, 0, 0, 0);
+      pg_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], ring[1], zero16, 0, 0, 0);
       ring[1] = nx[64];
       const int a0 = pg_or16(d0);
-      d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, ring[2], zero16, 0, 0, 0);
+      d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], ring[2], zero16, 0, 0, 0);
       ring[2] = nx[128];
       const int a1 = pg_or16(d1);
-      d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, ring[3], zero16, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], ring[3], zero16, 0, 0, 0);
       ring[3] = nx[192];
       const int a2 = pg_or16(d0);
       const int a3 = pg_or16(d1);
       ringS = Snext;
-      if (__builtin_amdgcn_ballot_w64((a0 | a1 | a2 | a3) < 0)) {
-        u32 tm = (__builtin_amdgcn_ballot_w64(a0 < 0) ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(a1 < 0) ? 2u : 0u) |
-                 (__builtin_amdgcn_ballot_w64(a2 < 0) ? 4u : 0u) | (__builtin_amdgcn_ballot_w64(a3 < 0) ? 8u : 0u);
-        while (tm) {                                        // ascending tiles: queue order = column order per row
-          const int i = __builtin_ctz(tm);
-          tm &= tm - 1;
-          extract_tile(S * 4 + i);
-        }
+      PG_ST(0, 1);
+      PG_ST(9, resweep);
+      if (!__builtin_amdgcn_ballot_w64((a0 | a1 | a2 | a3) < 0)) return false;
+      PG_ST(1, 1);
+      const u64 m0 = __builtin_amdgcn_ballot_w64(a0 < 0), m1 = __builtin_amdgcn_ballot_w64(a1 < 0);
+      const u64 m2 = __builtin_amdgcn_ballot_w64(a2 < 0), m3 = __builtin_amdgcn_ballot_w64(a3 < 0);
+      u32 tm = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
+      const int nslots = (int)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+      if (nslots >= p.mmDenseL1) return true;               // most lane slots hold a candidate: level 2 takes over
+      while (tm) {                                          // ascending tiles: queue order = column order per row
+        const int i = __builtin_ctz(tm);
+        tm &= tm - 1;
+        const int tile = S * 4 + i;
+        const pg_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], colsig[(long long)tile * 64 + lane], zero16, 0, 0, 0);
+        queue_from(d, tile);
       }
+      return false;
     };
 
-    // ---- direct form of one super-tile: whole column records in registers, every exact distance ----
-    auto row_direct = [&](const uint4 (&c)[C][Q], int rr, u32 col0) {
-      uint4 r[Q];
+    // ---- level 2: a run of super-tiles [S0, S1) with the signatures of planes 0..NP-1, one MFMA per
+    // plane and tile, the sign bits AND-ed (a pair can only be within the bound if it is within it in
+    // every plane).  The next tile's NP fragments are in flight while a tile is evaluated.  Returns the
+    // super-tile it stopped at: S1, or S0 when the run's first tile is dense at this level too (the
+    // caller then runs the direct form). ----
+    auto load_frags = [&](pg_v4i (&dst)[NP], int tile) {
+      const pg_v4i *src = colsig + (long long)tile * 64 + lane;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) r[q] = rows[rr * Q + q];
+      for (int pl = 0; pl < NP; ++pl) dst[pl] = src[pl * sigStride];
+    };
+    auto tile_level2 = [&](const pg_v4i (&b)[NP], int tile, bool probe) -> bool {
+      pg_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], b[0], zero16, 0, 0, 0);
+#pragma unroll
+      for (int pl = 1; pl < NP; ++pl) {                     // one plane at a time: two result sets live, not NP
+        __builtin_amdgcn_sched_barrier(0);
+        const pg_v16i t = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[pl], b[pl], zero16, 0, 0, 0);
+        d &= t;                                             // AND of the signs
+        asm volatile("" : "+v"(d));                         // keeps the chain sequential (no tree of result sets)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const u64 slots = __builtin_amdgcn_ballot_w64(pg_or16(d) < 0);
+      if (!slots) return false;
+      if (probe && __builtin_popcount((u32)slots) + __builtin_popcount((u32)(slots >> 32)) >= p.mmDenseL2) return true;
+      queue_from(d, tile);
+      return false;
+    };
+    // ---- direct form: whole column records in registers (two register sets, the next tile's loads in
+    // flight), every exact distance, one min + compare + branch per row-step ----
+    auto row_direct = [&](const uint4 (&c)[C][Q], const uint4 &r0, int rr, u32 col0) {
+      if constexpr (MODE == PG_MODE_KNN) {
+        if (resweep && !((failed >> rr) & 1u)) return;      // phase 1: frozen rows are final
+      }
+      uint4 r[Q];
+      r[0] = r0;
+#pragma unroll
+      for (int q = 1; q < Q; ++q) r[q] = rows[rr * Q + q];
       u32 d[C];
 #pragma unroll
       for (int b = 0; b < C; ++b) d[b] = M::dist(r, c[b], bias);
       u32 dmin = d[0];
 #pragma unroll
       for (int b = 1; b < C; ++b) dmin = dmin < d[b] ? dmin : d[b];
-      const u32 bound = kEps ? p.span + 1u : (__builtin_amdgcn_readlane(thrv, rr) >> 24) + (u32)resweep;
+      const u32 bound = kEps ? p.span + 1u : (__builtin_amdgcn_readlane(thrv, rr) >> 24) + resweep;
       if (__builtin_amdgcn_ballot_w64(dmin < bound)) {
 #pragma unroll
         for (int b = 0; b < C; ++b) epilogue(d[b], col0 + b * 64, rr);
       }
     };
-    auto sweep_direct = [&](int S) {
-#pragma unroll 1
-      for (int sub = 0; sub < PG_MM_ST / (64 * C); ++sub) {
-        const u32 col0 = (u32)(S * PG_MM_ST + sub * 64 * C) + lane;
-        uint4 c[C][Q];
+    auto load_cols = [&](uint4 (&dst)[C][Q], int dt) {     // direct tile dt: columns dt * 64 * C ..
 #pragma unroll
-        for (int b = 0; b < C; ++b)
+      for (int b = 0; b < C; ++b)
 #pragma unroll
-          for (int q = 0; q < Q; ++q) c[b][q] = colp[(long long)q * p.colNpad + col0 + b * 64];
-        for (int rr = 0; rr < nr; ++rr) row_direct(c, rr, col0);
-      }
+        for (int q = 0; q < Q; ++q) dst[b][q] = colp[(long long)q * p.colNpad + (long long)dt * (64 * C) + b * 64 + lane];
     };
-
-    // Adaptive choice per window of 8 super-tiles: when more than 1/5 of the window's pairs were
-    // queued, the exact evaluation of gathered candidates costs more than computing every distance
-    // of the tile in place; 120 super-tiles then run direct before the filter is probed again.
-    int win_st = 0, direct_left = 0;
-    auto sweep = [&](int S, int Snext) {
-      if (canFilter && (resweep || p.filter == 2 || direct_left == 0)) {
-        sweep_mfma(S, Snext);
-        if (++win_st == 8) {
-          if (p.filter == 1 && !resweep && wpush * 5 > nr * 8 * PG_MM_ST) direct_left = 120;
-          win_st = 0;
-          wpush = 0;
-        }
-        return;
+    auto rows_direct = [&](const uint4 (&c)[C][Q], int dt) {
+      const u32 col0 = (u32)(dt * (64 * C)) + lane;
+      uint4 ra = rows[0], rb = rows[Q];
+      for (int rr = 0; rr < nr; rr += 2) {
+        row_direct(c, ra, rr, col0);
+        ra = rows[(rr + 2 < RB ? rr + 2 : RB - 1) * Q];
+        if (rr + 1 < nr) row_direct(c, rb, rr + 1, col0);
+        rb = rows[(rr + 3 < RB ? rr + 3 : RB - 1) * Q];
       }
-      if (direct_left > 0) --direct_left;
-      while (qn > 0) flush();                               // in-place results must come after queued ones
-      sweep_direct(S);
     };
 
     // kNN checkpoints (first super-tile after them): after 1/32 of the sweep a row without any near
@@ -434,7 +490,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
           while (qn > 0) flush();
           const bool mine = lane < nr && !((failed >> (lane & 31)) & 1);
           u32 dref = thrv >> 24;                             // open lists read 255
-          if (snext != sw2) dref = mine ? lstbuf[wv][lane][p.knnFirst] >> 24 : 0u;
+          if (snext != sw2) dref = mine ? lstbuf[wv][lane & 31][p.knnFirst] >> 24 : 0u;
           const bool late = mine && dref >= G0;
           const u32 now = (u32)__builtin_amdgcn_ballot_w64(late);   // rows < 32
           if (now) {
@@ -447,13 +503,71 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
         }
       }
     };
+    auto run_direct = [&](int S0, int S1) {                 // super-tiles [S0, S1)
+      while (qn > 0) flush();                               // in-place results must come after queued ones
+      constexpr int F = PG_MM_ST / (64 * C);                // direct tiles per super-tile
+      const int t0 = S0 * F, t1 = S1 * F;
+      uint4 ca[C][Q], cb[C][Q];
+      load_cols(ca, t0);
+      for (int dt = t0; dt < t1; dt += 2) {
+        load_cols(cb, dt + 1 < t1 ? dt + 1 : dt);
+        rows_direct(ca, dt);
+        if ((dt + 1) % F == 0) checkpoint((dt + 1) / F);
+        if (dt + 1 < t1) {
+          load_cols(ca, dt + 2 < t1 ? dt + 2 : dt + 1);
+          rows_direct(cb, dt + 1);
+          if ((dt + 2) % F == 0) checkpoint((dt + 2) / F);
+        }
+      }
+    };
+
+    auto run_level2 = [&](int S0, int S1) -> int {
+      refresh_level2();
+      const int t0 = S0 * 4, t1 = S1 * 4;
+      pg_v4i ba[NP], bb[NP];
+      load_frags(ba, t0);
+      for (int t = t0; t < t1; t += 2) {                    // t1 - t0 is a multiple of four
+        load_frags(bb, t + 1);
+        if (tile_level2(ba, t, t == t0 && p.filter != 2)) return S0;   // filter == 2: never leave the filtered form (tests)
+        load_frags(ba, t + 2 < t1 ? t + 2 : t + 1);
+        tile_level2(bb, t + 1, false);
+        if (((t + 2) & 3) == 0) {
+          PG_ST(2, 1);
+          checkpoint((t + 2) >> 2);
+          refresh_level2();                                 // a checkpoint may have LOOSENED bounds (cap removed)
+        }
+      }
+      return S1;
+    };
 
     int send = nst;
     const int sbeg = kSym ? (int)(pr0 / PG_MM_ST) : 0;     // EPS_SYM: from the super-tile that holds the pass's first row
     for (;;) {
-      for (int S = sbeg; S < send; ++S) {
-        sweep(S, S + 1 < send ? S + 1 : S);
-        checkpoint(S + 1);
+      int S = sbeg;
+      while (S < send) {
+        bool direct = !canFilter;
+        int S1 = send;
+        if (canFilter) {
+          if (!sweep_mfma(S, S + 1 < send ? S + 1 : S)) {   // the common case: level 1 did the super-tile
+            checkpoint(S + 1);
+            ++S;
+            continue;
+          }
+          // level 1 is not selective here: a run at level 2, or direct when that is dense as well
+          S1 = S + p.mmDirectRun < send ? S + p.mmDirectRun : send;
+          const int stop = run_level2(S, S1);               // checkpoints inside
+          direct = stop == S;
+          S = stop;
+          ringS = -1;                                       // the fragments prefetched before the run are stale:
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ring[i] = pg_v4i{0, 0, 0, 0};   // dead across the run (frees their registers there)
+        }
+        if (direct) {
+          PG_ST(3, 1);
+          PG_ST(4, S1 - S);
+          run_direct(S, S1);                                // checkpoints inside
+          S = S1;
+        }
       }
       while (qn > 0) flush();
       if constexpr (MODE == PG_MODE_KNN) {
@@ -462,7 +576,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
         resweep = 1;
         set_all_bounds((lane < nr && ((failed >> (lane & 31)) & 1)) ? (thrv >> 24) + 1u : 0u);
         send = sredo;
-        win_st = 0; wpush = 0; direct_left = 0;
         ringS = -1;
       } else {
         break;
@@ -486,5 +599,13 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+#ifdef PG_MM_STATS
+  {
+    u32 v = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v = lane == i ? st[i] : v;
+    if (p.stats && lane < 12) atomicAdd(&p.stats[lane], (unsigned long long)v);
+  }
+#endif
 }
-
+#undef PG_ST
