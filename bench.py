@@ -5,6 +5,7 @@ roofline) for N x N Hamming + adjacency build").
 
   python bench.py --gpus 1 --steps K --warmup W            (default: configs[2], N=200k L=64 kNN16)
   python -m torch.distributed.run --nproc-per-node G ... bench.py --gpus G --steps K --warmup W
+                                                           (default for G > 1: configs[3], N=1M row-block sharded)
 
 A step = one pass of the hot path over one synthetic token matrix that is already resident in
 HBM as row-major uint8 (SURVEY.md §8-d generator): [all-gather of the row shards when G > 1] ->
@@ -14,14 +15,24 @@ slots + scan + CSR compaction).  Prints ONE JSON line on rank 0.
 Workloads (--workload):
   cfg3  N=200 000, L=64, kNN k=16        the configuration the target is quoted on (default, G=1)
   cfg2  N= 50 000, L=32, eps d<=2, full CSR
-  cfg3w the weak-scaling series anchored at cfg3 (default for G > 1): a square N_G x N_G problem with
-        N_G = 200 000 * sqrt(G), row-block sharded over G GPUs, so every GPU always evaluates 4.0e10
-        ordered pairs (G=1 is cfg3 itself, G=8 is N=565 688); the all-gather and the pack are in the step
-  cfg4  N=1 000 000, L=64, kNN k=16, row-block sharded: every GPU computes N/8 rows x N columns
-        (BASELINE.json configs[3]; G GPUs cover G/8 of the rows, G=8 is the full graph)
+  cfg4  N=1 000 000, L=64, kNN k=16, row-block sharded: every GPU computes N/8 = 125 000 rows x N columns
+        (BASELINE.json configs[3]; default for G > 1; G GPUs cover G/8 of the rows, G=8 is the full graph;
+        the all-gather and the pack are inside the step; PG_FORCE_DIST=1 runs the 1-GPU arm through RCCL)
+  cfg3w a square weak-scaling series anchored at cfg3: N_G = 200 000 * sqrt(G), row-block sharded
   cfg5  N=200 000, variable length 96..128, banded Levenshtein (band 8), kNN k=8 — build defined
+  cfg3d cfg3's shape on DENSE data (one cluster: a mutant library around one seed, every pair within 6)
+
+With one GPU and the default workload the line also carries `extra`: short runs of cfg2, cfg3d and
+cfg5 in the same invocation (their own ms_per_step / kernel_ms / value).
+
+roofline: the all-pairs kernel is bound by vector-instruction issue, not by HBM (the operand matrix is
+cache resident): `frac` = wave-instructions per second / the SIMD-32 issue peak, with the per-launch
+instruction count taken from the committed rocprofv3 PMC pass of the SAME kernel sources (sha
+checked, null otherwise) and the kernel time measured in THIS run.  The HBM-equivalent streaming rate
+of SURVEY.md §8-d (L bytes per ordered pair) is reported under `hbm_equivalent`, never as `frac`.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,11 +45,19 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+CUS, SIMDS, CLOCK_HZ = 256, 4, 2.4e9
+# MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles on a SIMD-32
+VALU_PEAK = CUS * SIMDS * CLOCK_HZ / 2.0          # 1.2288e12 wave-instructions/s
+# measured mixed-stream ceiling of this kernel's instruction classes (v_bcnt / v_cmp / v_or3 at ~4.2 cycles,
+# logic ops at ~2.3, profiles/r01_valu_issue_microbench.txt): reported beside the guide's peak
+VALU_MIX_CEILING = CUS * SIMDS * CLOCK_HZ / 4.2
+MFMA_I8_CYCLES = 32.0                              # v_mfma_i32_32x32x32_i8: cycles per instruction per SIMD
 
 WORKLOADS = {
     "cfg2": dict(N=50_000, L=32, mode="eps", eps=2, k=None, shards=1),
     "cfg3": dict(N=200_000, L=64, mode="knn", eps=None, k=16, shards=1),
-    "cfg3w": dict(N=200_000, L=64, mode="knn", eps=None, k=16, shards=1),     # N is scaled by sqrt(G) in main()
+    "cfg3d": dict(N=200_000, L=64, mode="knn", eps=None, k=16, shards=1, dense=True),
+    "cfg3w": dict(N=200_000, L=64, mode="knn", eps=None, k=16, shards=1),     # N is scaled by sqrt(G)
     "cfg4": dict(N=1_000_000, L=64, mode="knn", eps=None, k=16, shards=8),
     # build-defined (no reference counterpart, parity unpinned): variable length 96..128, band 8
     "cfg5": dict(N=200_000, L=128, mode="lev", eps=None, k=8, shards=1, band=8),
@@ -52,8 +71,21 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto"] + list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cfg2 / cfg3d / cfg5 sub-records")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU budget of the baseline sample")
     return ap.parse_args()
+
+
+def kernel_src_sha():
+    """sha of the kernel sources: PMC-derived numbers in profiles/pmc_summary.json are only quoted
+    for the build they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "prograph_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(tok_host, wl, budget_s):
@@ -102,45 +134,18 @@ def cpu_baseline_lev(tok_host, wl, budget_s):
                       "build-defined workload, no reference implementation exists"}
 
 
-def main():
-    a = parse()
-    # stdout must carry exactly ONE JSON line: park fd 1 on stderr while libraries (RCCL prints a
-    # version banner to stdout at communicator creation) run, restore it for the final print
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
-    G = a.gpus
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if G != world:
-        if world == 1 and G > 1:
-            raise SystemExit("--gpus > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        G = world
+class Ctx:
+    pass
+
+
+def run_workload(name, G, rank, dev, use_dist, backend, steps, warmup, want_pcie):
+    """Times `steps` steps of one workload; returns (record dict for rank 0, host tokens or None, wl)."""
     from prograph_amd import _native, synth, sharded
     import torch.distributed as dist
 
-    # PG_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
-    backend = os.environ.get("PG_DIST_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    use_dist = G > 1 or os.environ.get("PG_FORCE_DIST") == "1"      # PG_FORCE_DIST: rehearse the RCCL path with one rank
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    _native.lib()
-
-    name = a.workload if a.workload != "auto" else ("cfg3" if G == 1 else "cfg3w")
     wl = dict(WORKLOADS[name])
     if name == "cfg3w":
-        # weak scaling: N_G^2 / G = 200000^2 pairs per GPU, N_G a multiple of 8*G (equal row blocks)
-        unit = 8 * G
+        unit = 8 * G                      # N_G^2 / G = 200000^2 pairs per GPU, N_G a multiple of 8*G
         wl["N"] = int(-(-int(round(200_000 * (G ** 0.5))) // unit) * unit)
     N, L = wl["N"], wl["L"]
     if wl["shards"] > 1:
@@ -149,6 +154,7 @@ def main():
     else:
         lo, hi = sharded.row_block(N, G, rank)
     rows_local = hi - lo
+    members = N if wl.get("dense") else 256
 
     # synthetic input, resident in HBM before the timed region.  With G > 1 every rank owns its
     # row shard and the full matrix is all-gathered inside the step (the path's one collective).
@@ -159,47 +165,45 @@ def main():
         tok_dev = torch.from_numpy(tok_host).to(dev)
         shard_dev = None
     elif not use_dist:
-        tok_host = synth.clustered_tokens(N, L)
+        tok_host = synth.clustered_tokens(N, L, members=members)
         tok_dev = torch.from_numpy(tok_host).to(dev)
         shard_dev = None
     else:
         tok_host = None
+        tok_dev = None
         glo, ghi = sharded.row_block(N, G, rank)
-        shard_dev = torch.from_numpy(synth.clustered_tokens(N, L, row0=glo, nrows=ghi - glo)).to(dev)
+        shard_dev = torch.from_numpy(synth.clustered_tokens(N, L, row0=glo, nrows=ghi - glo, members=members)).to(dev)
 
     k = wl["k"] or 1
     cap = 256
-    if wl["mode"] == "lev":
-        pass
-    elif wl["mode"] == "eps":
+    L_ = _native.lib()
+    if wl["mode"] == "eps":
         slot_idx = torch.empty(rows_local * cap, dtype=torch.int32, device=dev)
         slot_w = torch.empty(rows_local * cap, dtype=torch.uint8, device=dev)
         counts = torch.empty(rows_local, dtype=torch.int32, device=dev)
-    else:
+    elif wl["mode"] == "knn":
         out = (torch.empty((rows_local, k), dtype=torch.int32, device=dev),
                torch.empty((rows_local, k), dtype=torch.uint8, device=dev))
     kern_ev = []
     result = {}
-
-    def step_lev(record):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        idx, d, st = _native.levenshtein_knn(tok_dev, k, band=wl["band"], cap=512, return_stats=True)
-        e1.record()
-        result.update(st)
-        if record:
-            kern_ev.append((e0, e1))
+    c = Ctx()
+    c.tok_dev = tok_dev
 
     def step(record):
-        if wl["mode"] == "lev":
-            return step_lev(record)
-        full = tok_dev if not use_dist else sharded.allgather_tokens(shard_dev, N)
-        planes = _native.pack(full, bits=5)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        if wl["mode"] == "lev":
+            e0.record()
+            idx, d, st = _native.levenshtein_knn(c.tok_dev, k, band=wl["band"], cap=512, return_stats=True)
+            e1.record()
+            result.update(st)
+            if record:
+                kern_ev.append((e0, e1))
+            return
+        full = c.tok_dev if not use_dist else sharded.allgather_tokens(shard_dev, N)
+        planes = _native.pack(full, bits=5)
         e0.record()
         if wl["mode"] == "eps" and lo == 0 and rows_local == N and os.environ.get("PG_EPS_SYM", "auto") != "0":
             # the whole square graph on one GPU: the symmetric path (what Prograph.build_graph takes)
-            L_ = _native.lib()
             counts_lo = torch.empty(rows_local, dtype=torch.int32, device=dev)
             sargs = (_native._ptr(planes.buf), planes.npad, planes.n, planes.g * 32, planes.bits, _native.CMP_LE,
                      float(wl["eps"]), cap, _native._ptr(slot_idx), _native._ptr(slot_w), _native._ptr(counts),
@@ -222,8 +226,7 @@ def main():
             _native.eps_slots_only(planes, planes, _native.CMP_LE, wl["eps"], lo, rows_local, cap, slot_idx, slot_w, counts)
             e1.record()
             indptr = torch.empty(rows_local + 1, dtype=torch.int64, device=dev)
-            scratch = torch.empty(int(_native.lib().pg_scan_scratch_bytes(rows_local)), dtype=torch.uint8, device=dev)
-            L_ = _native.lib()
+            scratch = torch.empty(int(L_.pg_scan_scratch_bytes(rows_local)), dtype=torch.uint8, device=dev)
             _native._check(L_.pg_exclusive_scan(_native._ptr(counts), rows_local, _native._ptr(indptr),
                                                 _native._ptr(scratch), _native._stream()), "scan")
             nnz = int(indptr[-1].item())
@@ -246,11 +249,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step(False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
@@ -261,10 +264,10 @@ def main():
 
     # PCIe-inclusive rate (never `value`): host numpy tokens -> HBM, one step, results -> host
     pcie_ms = None
-    if not use_dist:
+    if want_pcie and not use_dist:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        tok_dev = torch.from_numpy(tok_host).to(dev)
+        c.tok_dev = torch.from_numpy(tok_host).to(dev)
         step(False)
         if wl["mode"] == "knn":
             _ = out[0].cpu(), out[1].cpu()
@@ -272,57 +275,143 @@ def main():
         pcie_ms = (time.perf_counter() - t1) * 1e3
 
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in kern_ev]))
-    total_pairs = float(rows_local) * N * G                      # every rank does rows_local x N
-    ms_per_step = elapsed / a.steps * 1e3
-    value = total_pairs * a.steps / elapsed
+    ms_per_step = elapsed / steps * 1e3
+    value = float(rows_local) * N * G * steps / elapsed         # every rank does rows_local x N
+    engine = "mfma" if rows_local >= int(os.environ.get("PG_ENGINE_MIN_ROWS", "65536")) else "valu"
+    engine = os.environ.get("PG_ENGINE", engine)
+    rec = {"name": name, "N": N, "L": L, "k": k, "rows_local": rows_local, "kern_ms": kern_ms, "ms_per_step": ms_per_step,
+           "value": value, "pcie_ms": pcie_ms, "result": result, "engine": engine}
+    return rec, tok_host, wl
+
+
+def workload_text(rec, wl, G):
+    N, L, k = rec["N"], rec["L"], rec["k"]
+    kind = (f"kNN k={k}" if wl["mode"] == "knn" else
+            f"banded Levenshtein band={wl.get('band')} kNN k={k} (build defined, parity unpinned)" if wl["mode"] == "lev"
+            else f"eps d<={wl['eps']} full CSR")
+    data = ", dense data (one cluster)" if wl.get("dense") else ""
+    shard = (f", row-block sharded, {rec['rows_local']} rows/GPU x {N} columns, RCCL all-gather in step"
+             if G > 1 or wl["shards"] > 1 else "")
+    return f"{rec['name']}: N={N} L={L} {'Levenshtein' if wl['mode'] == 'lev' else 'Hamming'}, {kind}{data}{shard}"
+
+
+def roofline(rec, wl, pmc, sha):
+    """VALU-issue roofline of the dominant kernel, instruction counts from the committed PMC pass of
+    the same sources, time from this run."""
+    k, rows_local, N, L = rec["k"], rec["rows_local"], rec["N"], rec["L"]
+    out_bytes = 5 * k * rows_local if wl["mode"] in ("knn", "lev") else 8 * (rows_local + 1) + 5 * rec["result"].get("nnz", 0)
+    alg_bytes = float(rows_local) * N * L + rows_local * L + out_bytes      # SURVEY.md §8-d, per launch
+    hbm_eq = alg_bytes / (rec["kern_ms"] * 1e-3) / 1e9
+    p = pmc.get(rec["name"]) or {}
+    fresh = bool(p) and p.get("kernel_src_sha") == sha
+    valu = p.get("valu_wave_instr_per_launch") if fresh else None
+    mfma = p.get("mfma_instr_per_launch") if fresh else None
+    achieved = valu / (rec["kern_ms"] * 1e-3) if valu else None
+    r = {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instructions/s",
+         "frac": achieved / VALU_PEAK if achieved else None,
+         "traffic": p.get("hbm_bytes_per_launch") if fresh else None,
+         "kernel": p.get("kernel_name") if fresh else ("pg_mm_kernel" if rec["engine"] == "mfma" else "pg_nsq_kernel"),
+         "kernel_ms": rec["kern_ms"],
+         "valu_wave_instr_per_launch": valu,
+         "frac_of_measured_mix_ceiling": achieved / VALU_MIX_CEILING if achieved else None,
+         "mfma": None,
+         "hbm_equivalent": {"achieved_GBs": hbm_eq, "x_hbm_peak": hbm_eq / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
+                            "note": "SURVEY.md 8-d streaming rate (L bytes per ordered pair); the operand matrix is cache "
+                                    "resident, so this is not a fraction of any peak"},
+         "pmc_source": p.get("source") if fresh else None,
+         "pmc_kernel_src_sha": p.get("kernel_src_sha"), "kernel_src_sha": sha,
+         "note": "peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md); "
+                 "SQ_INSTS_VALU per launch is deterministic for a build + workload and comes from the committed rocprofv3 "
+                 "PMC pass (null when the kernel sources changed since); kernel_ms is this run's HIP-event time"}
+    if mfma:
+        r["mfma"] = {"instr_per_launch": mfma, "pipe_busy_frac": mfma * MFMA_I8_CYCLES / (CUS * SIMDS * CLOCK_HZ * rec["kern_ms"] * 1e-3),
+                     "note": "v_mfma_i32_32x32x32_i8 (stage-1 signature filter), 32 cycles per instruction per SIMD at 2.4 GHz"}
+    if wl["mode"] == "lev":
+        r["kernel"] = "pg_lev_* (profile + bag filter pg_nsq_kernel<BagMetric> + pg_lev_select_kernel)"
+        r["note"] = "kernel_ms spans the Levenshtein launches (filter + exact distances + selection); VALU-issue bound; " + r["note"]
+    return r
+
+
+def main():
+    a = parse()
+    # stdout must carry exactly ONE JSON line: park fd 1 on stderr while libraries (RCCL prints a
+    # version banner to stdout at communicator creation) run, restore it for the final print
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    G = a.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if G != world:
+        if world == 1 and G > 1:
+            raise SystemExit("--gpus > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        G = world
+    from prograph_amd import _native
+    import torch.distributed as dist
+
+    # PG_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get("PG_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    use_dist = G > 1 or os.environ.get("PG_FORCE_DIST") == "1"      # PG_FORCE_DIST: rehearse the RCCL path with one rank
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    _native.lib()
+
+    # one GPU: the headline configuration; several GPUs: BASELINE.json configs[3] (SURVEY.md §8-d weak scaling)
+    name = a.workload if a.workload != "auto" else ("cfg3" if G == 1 else "cfg4")
+    rec, tok_host, wl = run_workload(name, G, rank, dev, use_dist, backend, a.steps, a.warmup, want_pcie=True)
 
     if rank == 0:
-        out_bytes = 5 * k * rows_local if wl["mode"] in ("knn", "lev") else 8 * (rows_local + 1) + 5 * result.get("nnz", 0)
-        alg_bytes = float(rows_local) * N * L + rows_local * L + out_bytes      # SURVEY.md §8-d, per launch
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        # HBM traffic and VALU issue share are PMC measurements of this same command, collected in
-        # separate rocprofv3 passes (tools/profile.sh) and committed under profiles/
-        traffic = valu_frac = None
-        pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        sha = kernel_src_sha()
+        pmc = {}
+        pmc_path = os.path.join(REPO, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc_path):
             try:
-                rec = json.load(open(pmc)).get(name, {})
-                traffic, valu_frac = rec.get("hbm_bytes_per_launch"), rec.get("valu_issue_frac")
+                pmc = json.load(open(pmc_path))
             except Exception:
-                traffic = valu_frac = None
+                pmc = {}
         line = {
-            "metric": "sequence-pairs/s", "value": value, "unit": "sequence-pairs/s", "n_gpus": G,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "metric": "sequence-pairs/s", "value": rec["value"], "unit": "sequence-pairs/s", "n_gpus": G,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{name}: N={N} L={L} {'Levenshtein' if wl['mode'] == 'lev' else 'Hamming'}, " +
-                                   (f"kNN k={k}" if wl["mode"] == "knn" else
-                                    f"banded Levenshtein band={wl.get('band')} kNN k={k} (build defined, parity unpinned)" if wl["mode"] == "lev"
-                                    else f"eps d<={wl['eps']} full CSR") +
-                                   (f", row-block sharded, {rows_local} rows/GPU x {N} columns, RCCL all-gather in step" if G > 1 or wl["shards"] > 1 else ""),
-                       "N": N, "L": L, "rows_per_gpu": rows_local, "alphabet": "5-bit tokens 1..20",
-                       "parallelism": f"rowblock{G}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pg_nsq_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
-                         "note": "algorithmic bytes = L per ordered pair (SURVEY.md 8-d); the operand matrix is "
-                                 "cache resident so this HBM-equivalent rate is not capped at 1; the kernel is "
-                                 "VALU-issue bound: valu_frac = SQ_INSTS_VALU / time / (256 CUs x 4 SIMDs x 2.4 GHz / 4), "
-                                 "measured with rocprofv3 (profiles/pmc_summary.json)",
-                         "valu_frac": valu_frac},
+            "config": {"workload": workload_text(rec, wl, G), "N": rec["N"], "L": rec["L"], "rows_per_gpu": rec["rows_local"],
+                       "alphabet": "5-bit tokens 1..20", "parallelism": f"rowblock{G}", "engine": rec["engine"]},
+            "roofline": roofline(rec, wl, pmc, sha),
         }
         if wl["mode"] == "eps":
-            line["config"]["nnz"] = result.get("nnz")
-            if result.get("path"):
-                line["config"]["path"] = result["path"]
+            line["config"]["nnz"] = rec["result"].get("nnz")
+            if rec["result"].get("path"):
+                line["config"]["path"] = rec["result"]["path"]
         if wl["mode"] == "lev":
-            line["config"].update({"candidates": result.get("candidates"), "filter_passes": result.get("filter_passes")})
-            line["roofline"]["kernel"] = "pg_lev_* (profile + bag filter pg_nsq_kernel<BagMetric> + pg_lev_select_kernel)"
-            line["roofline"]["note"] = ("kernel_ms spans the three Levenshtein launches; algorithmic bytes = L per ordered pair as for "
-                                        "Hamming; the path is VALU bound (10 ops/pair filter + 4 ops/DP cell on candidates)")
-            line["roofline"]["valu_frac"] = None
-        if pcie_ms is not None:
-            line["pcie_inclusive"] = {"ms_per_step": pcie_ms, "value": float(rows_local) * N / (pcie_ms * 1e-3),
+            line["config"].update({"candidates": rec["result"].get("candidates"), "filter_passes": rec["result"].get("filter_passes")})
+        if rec["pcie_ms"] is not None:
+            line["pcie_inclusive"] = {"ms_per_step": rec["pcie_ms"], "value": float(rec["rows_local"]) * rec["N"] / (rec["pcie_ms"] * 1e-3),
                                       "note": "host tokens H2D + step + results D2H (pageable memory); reported only, not `value`"}
+        # the other single-GPU configurations, a few steps each, in the same invocation
+        if G == 1 and not use_dist and a.workload == "auto" and not a.no_extra:
+            extra = []
+            for sub in ("cfg2", "cfg3d", "cfg5"):
+                torch.cuda.empty_cache()
+                srec, _, swl = run_workload(sub, 1, 0, dev, False, backend, steps=5, warmup=2, want_pcie=False)
+                e = {"workload": workload_text(srec, swl, 1), "steps": 5, "warmup": 2, "ms_per_step": srec["ms_per_step"],
+                     "value": srec["value"], "unit": "sequence-pairs/s", "engine": srec["engine"],
+                     "roofline": roofline(srec, swl, pmc, sha)}
+                if swl["mode"] == "eps":
+                    e["nnz"] = srec["result"].get("nnz")
+                    e["path"] = srec["result"].get("path")
+                if swl["mode"] == "lev":
+                    e["candidates"] = srec["result"].get("candidates")
+                extra.append(e)
+            line["extra"] = extra
         if not use_dist and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tok_host, wl, a.cpu_seconds)
         else:

@@ -79,8 +79,14 @@ __device__ __forceinline__ int pg_or16(const pg_v16i &d) {
   return a | e;
 }
 
+// Records of up to three chunks (L <= 64 with 5 bit planes): held at 4 waves per SIMD (the kNN instance
+// would take 141 VGPRs; pinned to 128 it spills 7 of them outside the loops, measured faster)
 template <class M, int MODE>
+#ifndef PG_X_NOATTR
+__global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M::Q <= 3 ? 4 : 1, 8))) void pg_mm_kernel(const NsqParams p) {
+#else
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p) {
+#endif
   constexpr int Q = M::Q;
   constexpr int C = Q <= 4 ? 2 : 1;                        // direct form: columns per lane
   constexpr int NP = PG_MM_NP;
@@ -139,51 +145,43 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- row operands of the MFMAs, one per bit plane: lane l holds row l & 31, signature bits
-    // 16*(l >> 5) .. +15 of that plane; papack = the row's signature popcounts, 6 bits per plane ----
-    pg_v4i A[NP];
-    u32 papack = 0;
-    {
+    // ---- row operand of the level-1 MFMA: lane l holds row l & 31, plane-0 signature bits
+    // 16*(l >> 5) .. +15.  (The operands of planes 1.. are built when a level-2 run starts.) ----
+    auto row_operand = [&](int pl, u32 &pa) -> pg_v4i {
       uint4 rec[Q];
 #pragma unroll
       for (int q = 0; q < Q; ++q) rec[q] = rowbuf[wv][lane & 31][q];
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) {
-        const u32 s31 = pg_sig31(M::fold_plane(rec, pl));
-        papack |= (u32)__builtin_popcount(s31) << (6 * pl);
-        const u32 half = (s31 >> (16 * (lane >> 5))) & 0xFFFFu;
-        A[pl][0] = (int)pg_expand_pm1(half);
-        A[pl][1] = (int)pg_expand_pm1(half >> 4);
-        A[pl][2] = (int)pg_expand_pm1(half >> 8);
-        A[pl][3] = (int)pg_expand_pm1(half >> 12);
-      }
-    }
+      const u32 s31 = pg_sig31(M::fold_plane(rec, pl));
+      pa = (u32)__builtin_popcount(s31);
+      const u32 half = (s31 >> (16 * (lane >> 5))) & 0xFFFFu;
+      pg_v4i a;
+      a[0] = (int)pg_expand_pm1(half);
+      a[1] = (int)pg_expand_pm1(half >> 4);
+      a[2] = (int)pg_expand_pm1(half >> 8);
+      a[3] = (int)pg_expand_pm1(half >> 12);
+      return a;
+    };
+    u32 pa0;
+    pg_v4i A0 = row_operand(0, pa0);
     // A row's bound: lanes 32.. hold it in boundv (authoritative) and, as pa - bound clamped to int8,
-    // in the top byte of A[0][3] (k = 31).  A bound beyond pa + 128 passes everything either way.
+    // in the top byte of A0[3] (k = 31).  A bound beyond pa + 128 passes everything either way.
     u32 boundv = 0;
-    auto bias_byte = [&](int pl, u32 bound) -> u32 {
-      int b = (int)((papack >> (6 * pl)) & 63u) - (int)bound;
+    auto bias_byte = [&](u32 pa, u32 bound) -> u32 {
+      int b = (int)pa - (int)bound;
       b = b < -128 ? -128 : b;
       return ((u32)b & 0xFFu) << 24;
     };
     auto set_bound = [&](int row, u32 bound) {              // row, bound wave uniform
-      const u32 nb = ((u32)A[0][3] & 0x00FFFFFFu) | bias_byte(0, bound);
+      const u32 nb = ((u32)A0[3] & 0x00FFFFFFu) | bias_byte(pa0, bound);
       const bool me = lane == 32 + row;
-      A[0][3] = me ? (int)nb : A[0][3];
+      A0[3] = me ? (int)nb : A0[3];
       boundv = me ? bound : boundv;
     };
     auto set_all_bounds = [&](u32 bv) {                     // bv: lane r < 32 holds row r's bound
       const u32 g = (u32)__builtin_amdgcn_ds_bpermute((lane & 31) << 2, (int)bv);
-      const u32 nb = ((u32)A[0][3] & 0x00FFFFFFu) | bias_byte(0, g);
-      A[0][3] = (lane >= 32) ? (int)nb : A[0][3];
+      const u32 nb = ((u32)A0[3] & 0x00FFFFFFu) | bias_byte(pa0, g);
+      A0[3] = (lane >= 32) ? (int)nb : A0[3];
       boundv = g;
-    };
-    auto refresh_level2 = [&]() {                           // the other planes follow boundv only when level 2 runs
-#pragma unroll
-      for (int pl = 1; pl < NP; ++pl) {
-        const u32 nb = ((u32)A[pl][3] & 0x00FFFFFFu) | bias_byte(pl, boundv);
-        A[pl][3] = (lane >= 32) ? (int)nb : A[pl][3];
-      }
     };
 
     // Per-row state, lane indexed (lane = row in pass), touched with v_readlane / lane selects:
@@ -383,15 +381,15 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
         for (int i = 0; i < 4; ++i) ring[i] = colsig[(long long)(S * 4 + i) * 64 + lane];
       }
       const pg_v4i *nx = colsig + (long long)Snext * 4 * 64 + lane;
-      pg_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], ring[0], zero16, 0, 0, 0);
+      pg_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[0], zero16, 0, 0, 0);
       ring[0] = nx[0];
-      pg_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], ring[1], zero16, 0, 0, 0);
+      pg_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[1], zero16, 0, 0, 0);
       ring[1] = nx[64];
       const int a0 = pg_or16(d0);
-      d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], ring[2], zero16, 0, 0, 0);
+      d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[2], zero16, 0, 0, 0);
       ring[2] = nx[128];
       const int a1 = pg_or16(d1);
-      d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], ring[3], zero16, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[3], zero16, 0, 0, 0);
       ring[3] = nx[192];
       const int a2 = pg_or16(d0);
       const int a3 = pg_or16(d1);
@@ -409,7 +407,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
         const int i = __builtin_ctz(tm);
         tm &= tm - 1;
         const int tile = S * 4 + i;
-        const pg_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], colsig[(long long)tile * 64 + lane], zero16, 0, 0, 0);
+        const pg_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, colsig[(long long)tile * 64 + lane], zero16, 0, 0, 0);
         queue_from(d, tile);
       }
       return false;
@@ -425,12 +423,12 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) dst[pl] = src[pl * sigStride];
     };
-    auto tile_level2 = [&](const pg_v4i (&b)[NP], int tile, bool probe) -> bool {
-      pg_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], b[0], zero16, 0, 0, 0);
+    auto tile_level2 = [&](const pg_v4i (&Ax)[NP], const pg_v4i (&b)[NP], int tile, bool probe) -> bool {
+      pg_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, b[0], zero16, 0, 0, 0);
 #pragma unroll
       for (int pl = 1; pl < NP; ++pl) {                     // one plane at a time: two result sets live, not NP
         __builtin_amdgcn_sched_barrier(0);
-        const pg_v16i t = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[pl], b[pl], zero16, 0, 0, 0);
+        const pg_v16i t = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ax[pl], b[pl], zero16, 0, 0, 0);
         d &= t;                                             // AND of the signs
         asm volatile("" : "+v"(d));                         // keeps the chain sequential (no tree of result sets)
       }
@@ -441,6 +439,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
       queue_from(d, tile);
       return false;
     };
+
     // ---- direct form: whole column records in registers (two register sets, the next tile's loads in
     // flight), every exact distance, one min + compare + branch per row-step ----
     auto row_direct = [&](const uint4 (&c)[C][Q], const uint4 &r0, int rr, u32 col0) {
@@ -522,25 +521,42 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
     };
 
     auto run_level2 = [&](int S0, int S1) -> int {
-      refresh_level2();
+      // row operands of planes 1..NP-1, built per run from the rows in LDS (a run is >= 32 tiles of
+      // NP MFMAs: the ~25 VALU instructions per plane do not show, and 4 VGPRs per plane stay free
+      // everywhere else); their bias bytes follow boundv, which only level 1 keeps current
+      pg_v4i Ax[NP];
+      u32 pax[NP];
+      Ax[0] = A0;
+      pax[0] = pa0;
+#pragma unroll
+      for (int pl = 1; pl < NP; ++pl) Ax[pl] = row_operand(pl, pax[pl]);
+      auto refresh = [&]() {
+#pragma unroll
+        for (int pl = 1; pl < NP; ++pl) {
+          const u32 nb = ((u32)Ax[pl][3] & 0x00FFFFFFu) | bias_byte(pax[pl], boundv);
+          Ax[pl][3] = (lane >= 32) ? (int)nb : Ax[pl][3];
+        }
+      };
+      refresh();
       const int t0 = S0 * 4, t1 = S1 * 4;
       pg_v4i ba[NP], bb[NP];
       load_frags(ba, t0);
       for (int t = t0; t < t1; t += 2) {                    // t1 - t0 is a multiple of four
         load_frags(bb, t + 1);
-        if (tile_level2(ba, t, t == t0 && p.filter != 2)) return S0;   // filter == 2: never leave the filtered form (tests)
+        if (tile_level2(Ax, ba, t, t == t0 && p.filter != 2)) return S0;   // filter == 2: never leave the filtered form (tests)
         load_frags(ba, t + 2 < t1 ? t + 2 : t + 1);
-        tile_level2(bb, t + 1, false);
+        tile_level2(Ax, bb, t + 1, false);
         if (((t + 2) & 3) == 0) {
           PG_ST(2, 1);
           checkpoint((t + 2) >> 2);
-          refresh_level2();                                 // a checkpoint may have LOOSENED bounds (cap removed)
+          refresh();                                        // a checkpoint may have LOOSENED bounds (cap removed)
         }
       }
       return S1;
     };
 
     int send = nst;
+    int drun = p.mmDirectRun;                               // super-tiles per level-2 / direct run
     const int sbeg = kSym ? (int)(pr0 / PG_MM_ST) : 0;     // EPS_SYM: from the super-tile that holds the pass's first row
     for (;;) {
       int S = sbeg;
@@ -554,9 +570,11 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
             continue;
           }
           // level 1 is not selective here: a run at level 2, or direct when that is dense as well
-          S1 = S + p.mmDirectRun < send ? S + p.mmDirectRun : send;
+          S1 = S + drun < send ? S + drun : send;
           const int stop = run_level2(S, S1);               // checkpoints inside
           direct = stop == S;
+          // direct runs back off (8, 16, .. 64 super-tiles) while every probe finds level 2 dense as well
+          drun = direct ? (drun * 2 < 8 * p.mmDirectRun ? drun * 2 : 8 * p.mmDirectRun) : p.mmDirectRun;
           S = stop;
           ringS = -1;                                       // the fragments prefetched before the run are stale:
 #pragma unroll

@@ -2,22 +2,50 @@
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_src_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "prograph_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def newest(pattern):
+    """one CSV per rerun accumulates in a trace directory: take the most recent"""
+    fs = glob.glob(pattern, recursive=True)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+
+def engine_kernel(name):
+    return "pg_nsq_kernel" in name or "pg_mm_kernel" in name
+
 out_dir, wl = sys.argv[1], sys.argv[2]
-res = {"workload": wl, "kernel": None, "counters": {}, "command": f"python bench.py --workload {wl} --no-cpu-baseline"}
-for f in glob.glob(f"{out_dir}/trace/**/*_kernel_stats.csv", recursive=True):
+res = {"workload": wl, "kernel": None, "counters": {}, "command": f"python bench.py --workload {wl} --no-cpu-baseline --no-extra",
+       "kernel_src_sha": kernel_src_sha()}
+for f in newest(f"{out_dir}/trace/**/*_kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
     for r in rows:
-        if "pg_nsq_kernel" in r["Name"]:
+        if engine_kernel(r["Name"]) and (res["kernel"] is None or float(r["Percentage"]) > res["kernel"]["pct"]):
             res["kernel"] = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                              "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
     res["all_kernels"] = [{"name": r["Name"][:80], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])} for r in rows]
-for f in glob.glob(f"{out_dir}/pmc_*/**/*_counter_collection.csv", recursive=True):
+pmc_files = []
+for d in sorted(glob.glob(f"{out_dir}/pmc_*")):
+    pmc_files += newest(f"{d}/**/*_counter_collection.csv")
+for f in pmc_files:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "pg_nsq_kernel" in r["Kernel_Name"]:
+        if res["kernel"] and r["Kernel_Name"] == res["kernel"]["name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             res["vgpr"] = int(r["VGPR_Count"]); res["sgpr"] = int(r["SGPR_Count"]); res["lds"] = int(r["LDS_Block_Size"])
             res["grid"] = int(r["Grid_Size"]); res["wg"] = int(r["Workgroup_Size"])
@@ -34,7 +62,10 @@ if "GRBM_GUI_ACTIVE" in c and res["kernel"]:
     res["clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / res["kernel"]["avg_ns"]
 if "SQ_INSTS_VALU" in c and res["kernel"]:
     res["valu_wave_instr_per_s"] = c["SQ_INSTS_VALU"] / (res["kernel"]["avg_ns"] * 1e-9)
-    res["valu_issue_frac_of_peak"] = res["valu_wave_instr_per_s"] / (256 * 4 * 2.4e9 / 4)
+    res["valu_issue_frac_of_peak"] = res["valu_wave_instr_per_s"] / (256 * 4 * 2.4e9 / 2)   # SIMD-32: 2 cycles per wave64 instruction
+    res["valu_issue_frac_of_4cycle_rate"] = res["valu_wave_instr_per_s"] / (256 * 4 * 2.4e9 / 4)
+if "SQ_INSTS_MFMA" in c and res["kernel"]:
+    res["mfma_pipe_busy_frac"] = c["SQ_INSTS_MFMA"] * 32.0 / (256 * 4 * 2.4e9 * res["kernel"]["avg_ns"] * 1e-9)
 if "TCC_HIT_sum" in c:
     res["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
 print(json.dumps(res, indent=1))
