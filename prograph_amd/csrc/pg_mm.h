@@ -354,23 +354,43 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
     auto queue_from = [&](const pg_v16i &d, int tile) {
       PG_ST(5, 1);
       const u32 ebase = ((4u * (u32)(lane >> 5)) << SH) | (u32)(tile * 32 + (lane & 31));
-      u32 done = 0;                                         // result registers already queued
-      do {
+      int total = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) total += (int)__popcll(__builtin_amdgcn_ballot_w64(d[r] < 0));
+      PG_ST(6, total);
+      u32 done = 0xFFFFu;                                   // result registers already queued
+      if (qn + total <= PG_MM_QCAP) {
+        // the usual case (a tile holds a dozen candidates): everything fits, straight-line pushes
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (((done >> r) & 1u) == 0 && qn < 64) {
-            done |= 1u << r;
-            const bool hit = d[r] < 0;
-            const u64 mb = __builtin_amdgcn_ballot_w64(hit);
-            if (mb) {
-              if (hit) cq[qn + mask_rank(mb)] = ebase + ((u32)((r & 3) + 8 * (r >> 2)) << SH);
-              qn += __builtin_popcount((u32)mb) + __builtin_popcount((u32)(mb >> 32));
-              PG_ST(6, __popcll(mb));
+          const bool hit = d[r] < 0;
+          const u64 mb = __builtin_amdgcn_ballot_w64(hit);
+          if (mb) {
+            if (hit) cq[qn + mask_rank(mb)] = ebase + ((u32)((r & 3) + 8 * (r >> 2)) << SH);
+            qn += (int)__popcll(mb);
+          }
+        }
+      } else {
+        done = 0;                                           // a crowded tile: register by register below
+      }
+      for (;;) {
+        if (done != 0xFFFFu) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (((done >> r) & 1u) == 0 && qn < 64) {
+              done |= 1u << r;
+              const bool hit = d[r] < 0;
+              const u64 mb = __builtin_amdgcn_ballot_w64(hit);
+              if (mb) {
+                if (hit) cq[qn + mask_rank(mb)] = ebase + ((u32)((r & 3) + 8 * (r >> 2)) << SH);
+                qn += (int)__popcll(mb);
+              }
             }
           }
         }
-        if (qn >= 64) flush();
-      } while (done != 0xFFFFu);
+        while (qn >= 64) flush();                           // the only flush site of the queueing code
+        if (done == 0xFFFFu) break;
+      }
     };
     pg_v4i ring[4];
     int ringS = -1;                                         // super-tile whose fragments the ring holds
@@ -539,16 +559,17 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
       };
       refresh();
       const int t0 = S0 * 4, t1 = S1 * 4;
-      pg_v4i ba[NP], bb[NP];
-      load_frags(ba, t0);
-      for (int t = t0; t < t1; t += 2) {                    // t1 - t0 is a multiple of four
-        load_frags(bb, t + 1);
-        if (tile_level2(Ax, ba, t, t == t0 && p.filter != 2)) return S0;   // filter == 2: never leave the filtered form (tests)
-        load_frags(ba, t + 2 < t1 ? t + 2 : t + 1);
-        tile_level2(Ax, bb, t + 1, false);
-        if (((t + 2) & 3) == 0) {
+      pg_v4i bc[NP], bn[NP];                                // this tile's fragments, the next tile's (in flight)
+      load_frags(bc, t0);
+#pragma unroll 1
+      for (int t = t0; t < t1; ++t) {
+        load_frags(bn, t + 1 < t1 ? t + 1 : t);
+        if (tile_level2(Ax, bc, t, t == t0 && p.filter != 2)) return S0;   // filter == 2: never leave the filtered form (tests)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) bc[pl] = bn[pl];
+        if (((t + 1) & 3) == 0) {
           PG_ST(2, 1);
-          checkpoint((t + 2) >> 2);
+          checkpoint((t + 1) >> 2);
           refresh();                                        // a checkpoint may have LOOSENED bounds (cap removed)
         }
       }
