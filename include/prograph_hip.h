@@ -245,14 +245,17 @@ int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const void *
 
 /*
  * pg_csr_row_stats — per-row reductions over a CSR graph for the analytics that consume the
- * `Neighbours` column (prograph/prograph.py:797-946: degree, dirichlet, local_variance):
- *   deg[r] = sum_j w_rj,  sum_f[r] = sum_j f[col_j],  sum_wf[r] = sum_j w_rj * f[col_j]
+ * `Neighbours` column (prograph/prograph.py:797-946: degree, laplacian, dirichlet, local_variance):
+ *   deg[r] = sum_j w_rj,  sum_f[r] = sum_j f[col_j],  sum_wf[r] = sum_j w_rj * f[col_j],
+ *   self_w[r] = weight of the entry whose column is the row's own node row0 + r (kNN lists of
+ *   duplicated sequences contain it; the reference's Laplacian overwrites that diagonal term,
+ *   prograph.py:894-896),  col_sum[c] += w_rc (in-degree, `mode="indegree"`; caller zeroes it).
  * weights: uint8 distances OR float32 (exactly one non-NULL; both NULL = boolean weights 1);
  * f = per-node values (double[ncols]); any output may be NULL.
  */
 int pg_csr_row_stats(const int64_t *indptr, const int32_t *indices, const uint8_t *weights_u8,
-                     const float *weights_f32, int64_t nrows, const double *f, double *deg,
-                     double *sum_f, double *sum_wf, void *stream);
+                     const float *weights_f32, int64_t nrows, int64_t row0, const double *f, double *deg,
+                     double *sum_f, double *sum_wf, double *self_w, double *col_sum, void *stream);
 
 /*
  * pg_compact_flags — ascending indices of the non-zero flags (np.where(...)[0]).

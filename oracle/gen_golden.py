@@ -119,6 +119,21 @@ def make_csv(tmp, name, tokens, seed):
     return p
 
 
+def store_analytics(d, pg, graph, prefix):
+    """Graph-signal quantities of the REAL reference for one stored graph column (prograph/prograph.py:
+    797-946): degree, Laplacian diagonal (both degree modes), Dirichlet energy, local variance -
+    weighted and boolean.  The device path (pg_csr_row_stats) is checked against these."""
+    import warnings
+    for bw, tag in ((False, "w"), (True, "b")):
+        d[f"{prefix}_deg_{tag}"] = np.asarray(pg.degree(graph, boolean_weights=bw))
+        for mode in ("outdegree", "indegree"):
+            d[f"{prefix}_lapdiag_{tag}_{mode[:3]}"] = np.asarray(pg.laplacian(graph, boolean_weights=bw, mode=mode).diagonal(), dtype=np.float64)
+            d[f"{prefix}_dirichlet_{tag}_{mode[:3]}"] = np.asarray(pg.dirichlet(graph, boolean_weights=bw, mode=mode), dtype=np.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        d[f"{prefix}_locvar"] = np.asarray(pg.local_variance(graph), dtype=np.float64)
+
+
 def gen_reference_csv():
     os.chdir(REF)
     pg = quiet(Prograph, file="data/synthetic_data.csv")
@@ -156,6 +171,15 @@ def gen_reference_csv():
     d["calc_neigh_ACL_le2"] = pg.calc_neighbours(seq="ACL", eps=2, comp=operator.le)
     d["degree"] = pg.degree()
     d["adj33"] = np.asarray(pg.adjacency().todense()[:3, :3])
+    store_analytics(d, pg, "Neighbours", "ana_eps1")
+    proxy.stable = True
+    pg.graph["K5"] = quiet(pg.build_graph, k=5)
+    pg.graph["K4s"] = quiet(pg.build_graph, k=4, similarity=True)
+    proxy.stable = False
+    pg.graph["E2s"] = quiet(pg.build_graph, eps=2, similarity=True)
+    store_analytics(d, pg, "K5", "ana_knn5")
+    store_analytics(d, pg, "K4s", "ana_knn4sim")
+    store_analytics(d, pg, "E2s", "ana_eps2sim")
     dd = ref_hamming(pg.tokenized, pg.tokenized[pg.query(pg.seed.Sequence)].reshape(1, -1))
     d["str_maxdist"] = np.int64(int(torch.max(dd)))
     d["str_ndist"] = np.int64(len(np.unique(dd)))
@@ -234,6 +258,16 @@ def main():
             d["sub_idxs"] = sub
             store_eps(d, "eps2_sub", quiet(pg.build_graph, eps=2, idxs=sub))
             store_knn(d, "knn3_sub", pg, k=3, idxs=sub)
+            # duplicates + kNN + similarity: rows whose list contains the row itself (Laplacian setdiag case)
+            d["fitness"] = pg("Fitness").to_numpy()
+            store_analytics(d, pg, "Neighbours", "ana_eps1")
+            proxy.stable = True
+            pg.graph["K3s"] = quiet(pg.build_graph, k=3, similarity=True)
+            pg.graph["K16"] = quiet(pg.build_graph, k=16)
+            proxy.stable = False
+            store_knn(d, "knn3_sim", pg, k=3, similarity=True)
+            store_analytics(d, pg, "K3s", "ana_knn3sim")
+            store_analytics(d, pg, "K16", "ana_knn16")
         gen_set(tmp, "synth_n515_l20_dups", t3, 13, [2, 3], [1, 16, 40], extra=extra3)
 
         t4, l4 = synth.clustered_varlen_tokens(300, Lmax=24, Lmin=12, seed=synth.DEFAULT_SEED + 3, members=50)

@@ -93,7 +93,7 @@ def _load():
                                              _vp, _vp]
         lib.pg_index_flags.argtypes = [_vp, _i64, _i64, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_compact_flags.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
-        lib.pg_csr_row_stats.argtypes = [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]
+        lib.pg_csr_row_stats.argtypes = [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_lev_profile.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp]
         lib.pg_lev_candidates.argtypes = [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]
         lib.pg_lev_candidates_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -461,19 +461,23 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
     return idx, dist
 
 
-def csr_row_stats(indptr, indices, weights, f=None, want=("deg",)):
+def csr_row_stats(indptr, indices, weights, f=None, want=("deg",), row0=0, ncols=None):
     """Per-row reductions over a device CSR (see pg_csr_row_stats).  `weights`: uint8 or float32
-    device tensor or None (boolean).  Returns a dict of float64 device tensors."""
+    device tensor or None (boolean).  `want` from deg / sum_f / sum_wf / self_w (per row) and col_sum
+    (per column, needs `ncols`).  Returns a dict of float64 device tensors."""
     nrows = indptr.numel() - 1
     dev = indptr.device
-    out = {k: torch.empty(nrows, dtype=torch.float64, device=dev) for k in want}
+    out = {k: torch.empty(nrows, dtype=torch.float64, device=dev) for k in want if k != "col_sum"}
+    if "col_sum" in want:
+        out["col_sum"] = torch.zeros(int(ncols), dtype=torch.float64, device=dev)
     w8 = weights if (weights is not None and weights.dtype == torch.uint8) else None
     wf = weights if (weights is not None and weights.dtype == torch.float32) else None
     if weights is not None and w8 is None and wf is None:
         raise TypeError("weights must be uint8 or float32")
     fd = None if f is None else f.to(device=dev, dtype=torch.float64).contiguous()
-    _check(lib().pg_csr_row_stats(_ptr(indptr), _ptr(indices), _ptr(w8), _ptr(wf), nrows, _ptr(fd), _ptr(out.get("deg")),
-                                  _ptr(out.get("sum_f")), _ptr(out.get("sum_wf")), _stream()), "pg_csr_row_stats")
+    _check(lib().pg_csr_row_stats(_ptr(indptr), _ptr(indices), _ptr(w8), _ptr(wf), nrows, int(row0), _ptr(fd),
+                                  _ptr(out.get("deg")), _ptr(out.get("sum_f")), _ptr(out.get("sum_wf")),
+                                  _ptr(out.get("self_w")), _ptr(out.get("col_sum")), _stream()), "pg_csr_row_stats")
     return out
 
 

@@ -268,23 +268,27 @@ __global__ __launch_bounds__(256) void pg_csr_row_stats_kernel(const long long *
                                                                const int *__restrict__ indices,
                                                                const unsigned char *__restrict__ w8,
                                                                const float *__restrict__ wf, long long nrows,
-                                                               const double *__restrict__ f, double *deg, double *sf,
-                                                               double *swf) {
+                                                               long long row0, const double *__restrict__ f, double *deg,
+                                                               double *sf, double *swf, double *selfw, double *colsum) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nrows) return;
   const long long a = indptr[row], b = indptr[row + 1];
-  double d = 0, s1 = 0, s2 = 0;
+  double d = 0, s1 = 0, s2 = 0, sw = 0;
   for (long long e = a + lane; e < b; e += 64) {
     const double w = w8 ? (double)w8[e] : (wf ? (double)wf[e] : 1.0);
-    const double fj = f ? f[indices[e]] : 0.0;
+    const int col = indices[e];
+    const double fj = f ? f[col] : 0.0;
     d += w; s1 += fj; s2 += w * fj;
+    if (col == row0 + row) sw += w;                       // the row's own node among its neighbours
+    if (colsum) atomicAdd(&colsum[col], w);               // in-degree (column sums of the adjacency)
   }
-  d = wave_sum(d); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  d = wave_sum(d); s1 = wave_sum(s1); s2 = wave_sum(s2); sw = wave_sum(sw);
   if (lane == 0) {
     if (deg) deg[row] = d;
     if (sf) sf[row] = s1;
     if (swf) swf[row] = s2;
+    if (selfw) selfw[row] = sw;
   }
 }
 
@@ -754,11 +758,12 @@ int pg_lev_knn(const uint8_t *tokens, int64_t n, int l, int64_t ld, const void *
 }
 
 int pg_csr_row_stats(const int64_t *indptr, const int32_t *indices, const uint8_t *weights_u8, const float *weights_f32,
-                     int64_t nrows, const double *f, double *deg, double *sum_f, double *sum_wf, void *stream) {
-  if (!indptr || !indices || nrows <= 0) return fail(PG_E_BADARG, "pg_csr_row_stats: bad argument");
+                     int64_t nrows, int64_t row0, const double *f, double *deg, double *sum_f, double *sum_wf,
+                     double *self_w, double *col_sum, void *stream) {
+  if (!indptr || !indices || nrows <= 0 || row0 < 0) return fail(PG_E_BADARG, "pg_csr_row_stats: bad argument");
   if ((sum_f || sum_wf) && !f) return fail(PG_E_BADARG, "pg_csr_row_stats: node values required");
   pg_csr_row_stats_kernel<<<dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
-      (const long long *)indptr, indices, weights_u8, weights_f32, nrows, f, deg, sum_f, sum_wf);
+      (const long long *)indptr, indices, weights_u8, weights_f32, nrows, row0, f, deg, sum_f, sum_wf, self_w, col_sum);
   return launched((int)hipGetLastError(), "pg_csr_row_stats_kernel");
 }
 

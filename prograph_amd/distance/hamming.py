@@ -15,6 +15,8 @@ distances the kernel accumulates into the same (M, N) matrix.  Anything else is 
 sequence data (floats with fractions, wide integers) and is evaluated with the same torch
 expression as the reference, on the GPU; there is no CPU path.
 """
+import weakref
+
 import torch
 
 from .. import _native
@@ -23,18 +25,27 @@ from .utils import clean_input
 # The reference calls distance(X, batch) once per batch of 8 rows with the SAME X
 # (prograph/prograph.py:731-732): remember, for the last few X operands that live on the device,
 # whether they are byte tokens, their largest token and their packed form, so that such loops
-# validate and pack the big matrix once.  Keyed on storage identity + in-place version counter.
+# validate and pack the big matrix once.  An entry belongs to ONE tensor object: it holds a weak
+# reference to it and only answers for that very object at the same in-place version (storage
+# addresses are reused by the caching allocator, so address + shape alone would hand a freed
+# operand's distances to the next tensor allocated in its place).
 _X_CACHE = {}
 _X_CACHE_MAX = 4
 
 
 def _x_entry(X, Xd, cacheable):
-    key = (X.data_ptr(), tuple(X.shape), X.dtype, X._version, str(X.device)) if cacheable else None
+    key = (X.data_ptr(), tuple(X.shape), X.dtype, str(X.device)) if cacheable else None
+    for k in [k for k, e in _X_CACHE.items() if e["ref"]() is None]:
+        del _X_CACHE[k]                                    # operands that died
     ent = _X_CACHE.get(key) if key is not None else None
+    if ent is not None and (ent["ref"]() is not X or ent["version"] != X._version):
+        del _X_CACHE[key]                                  # another tensor at that address, or edited in place
+        ent = None
     if ent is None:
         xb = _as_byte_tokens(Xd)
         ent = {"xb": xb, "max": int(xb.max()) if xb is not None else None, "planes": {}}
         if key is not None:
+            ent["ref"], ent["version"] = weakref.ref(X), X._version
             if len(_X_CACHE) >= _X_CACHE_MAX:
                 _X_CACHE.pop(next(iter(_X_CACHE)))
             _X_CACHE[key] = ent

@@ -57,8 +57,10 @@ class CSRGraph:
         return self.weights
 
     def row_stats(self, f=None, boolean_weights=False, want=("deg",)):
-        """Device reductions per row (pg_csr_row_stats): deg = sum w, sum_f = sum f[col], sum_wf = sum w f[col]."""
-        return _native.csr_row_stats(self.indptr, self.indices, self._w(boolean_weights), f=f, want=want)
+        """Device reductions (pg_csr_row_stats): per row deg = sum w, sum_f = sum f[col], sum_wf = sum w f[col],
+        self_w = weight of the row's own node in its list; per column col_sum = sum of the column's weights."""
+        return _native.csr_row_stats(self.indptr, self.indices, self._w(boolean_weights), f=f, want=want,
+                                     row0=self.row0, ncols=self.ncols)
 
     def degree(self, boolean_weights=False):
         """Out-degree per row as float32 (prograph.py:797-822) without touching Python tuples."""
@@ -66,15 +68,34 @@ class CSRGraph:
             return (self.indptr[1:] - self.indptr[:-1]).to(torch.float32).cpu().numpy()
         return self.row_stats(want=("deg",))["deg"].to(torch.float32).cpu().numpy()
 
-    def dirichlet(self, f, boolean_weights=False):
-        """f^T L f with L = D_out - A (prograph.py:874-922), f = per-node values of the ROWS' nodes
-        (square graph: nrows == ncols)."""
+    def _degree_vector(self, st, mode):
+        """The Laplacian's diagonal D as the reference builds it (prograph.py:887-896): out-degree = row
+        sums kept in float32 (`degree()`), in-degree = column sums of the float32 adjacency."""
+        if mode == "outdegree":
+            return st["deg"].to(torch.float32).to(torch.float64)
+        if mode == "indegree":
+            return st["col_sum"][self.row0:self.row0 + self.nrows].to(torch.float32).to(torch.float64)
+        raise ValueError("Not a valid degree mode.")
+
+    def laplacian_diagonal(self, boolean_weights=False, mode="outdegree"):
+        want = ("deg",) if mode == "outdegree" else ("col_sum",)
+        if mode not in ("outdegree", "indegree"):
+            raise ValueError("Not a valid degree mode.")
+        return self._degree_vector(self.row_stats(boolean_weights=boolean_weights, want=want), mode).cpu().numpy()
+
+    def dirichlet(self, f, boolean_weights=False, mode="outdegree"):
+        """f^T L f with L = -A, diagonal OVERWRITTEN by D (`L.setdiag(D)`, prograph.py:887-896): a row's own
+        node in its neighbour list (kNN with duplicated sequences) does not enter the off-diagonal sum.
+        f = per-node values of the ROWS' nodes (square graph: nrows == ncols)."""
+        if mode not in ("outdegree", "indegree"):
+            raise ValueError("Not a valid degree mode.")
         fd = torch.as_tensor(np.asarray(f, dtype=np.float64).reshape(-1), device=self.indptr.device)
-        st = self.row_stats(f=fd, boolean_weights=boolean_weights, want=("deg", "sum_wf"))
+        want = ("deg", "sum_wf", "self_w") + (("col_sum",) if mode == "indegree" else ())
+        st = self.row_stats(f=fd, boolean_weights=boolean_weights, want=want)
         fr = fd[self.row0:self.row0 + self.nrows]
-        # the reference keeps the degree in float32 (prograph.py:815) before it enters the Laplacian
-        deg = st["deg"].to(torch.float32).to(torch.float64)
-        return float((fr * (deg * fr - st["sum_wf"])).sum().item())
+        D = self._degree_vector(st, mode)
+        off = st["sum_wf"] - st["self_w"] * fr                # sum over j != r of A_rj f_j
+        return float((fr * (D * fr - off)).sum().item())
 
     def local_variance(self, f):
         """mean_j (f_r - f_j) over the row's neighbours (prograph.py:924-946); NaN for empty rows."""

@@ -74,6 +74,7 @@ class Prograph:
         self.sequence_mutation_locations = self.boolean_mutant_array(self.seed.Sequence)
         self.mutation_arrays = self.gen_mutation_arrays()
         self.csr_graphs = {}         # name -> CSRGraph / KNNGraph kept on the device
+        self._csr_rows = {}          # name -> row objects of the column the device graph answers for
 
         if "Tokenized" not in self.graph:
             self.graph["Tokenized"] = list(self.tokenized)
@@ -228,9 +229,12 @@ class Prograph:
 
     # ------------------------------------------------------------------ device residency
     def _byte_planes(self, representation="Tokenized", idxs=None):
-        """Plane layout of a byte-token representation on the GPU (cached for the full matrix)."""
+        """Plane layout of a byte-token representation on the GPU.  Only the token matrix of the
+        constructor is cached (`self.tokenized` never changes); any other representation is a
+        DataFrame column the user may reassign (`embedding()`, `pg.graph[name] = ...`) and is read and
+        packed on every call, as the reference re-reads `self(representation)` (prograph.py:726)."""
         key = representation
-        if idxs is None and key in self._planes:
+        if idxs is None and key == "Tokenized" and key in self._planes:
             return self._planes[key]
         if representation == "Tokenized":
             mat = self.tokenized
@@ -244,7 +248,7 @@ class Prograph:
         # tokens of the built-in tokeniser are 0..len(amino_acids): 5 bit planes cover 31 letters
         bits = _native.BITS_5 if (representation == "Tokenized" and len(self.amino_acids) <= 31) else None
         planes = _native.pack(torch.from_numpy(np.ascontiguousarray(mat)), rows=idxs, bits=bits)
-        if idxs is None:
+        if idxs is None and key == "Tokenized":
             self._planes[key] = planes
         return planes
 
@@ -450,12 +454,20 @@ class Prograph:
         else:
             idx, dist = _native.knn_graph(planes, planes, k)
             g = KNNGraph(idx, dist, planes.n, similarity=similarity)
+        tuples = None
         if store is not None and idxs is None:
-            self.graph[store] = g.to_tuples()
+            tuples = g.to_tuples()
+            self.graph[store] = tuples
             _keep = store
         if _keep is not None and idxs is None:
+            if tuples is None:
+                tuples = g.to_tuples()
             self.csr_graphs[_keep] = g
-        return g if output == "csr" else g.to_tuples()
+            # the device CSR answers for the column only while the column still holds THESE row objects
+            self._csr_rows[_keep] = (tuples[0], tuples[len(tuples) // 2], tuples[-1]) if tuples else ()
+        if output == "csr":
+            return g
+        return tuples if tuples is not None else g.to_tuples()
 
     def _build_graph_generic(self, idxs, batch_size, eps, k, similarity, representation, distance, comp):
         """
@@ -503,8 +515,13 @@ class Prograph:
         col = self.graph[graph]
         if len(col) != g.nrows or g.nrows != g.ncols:
             return None
-        for r in (0, g.nrows - 1):
-            if len(col.iloc[r][0]) != int(g.indptr[r + 1] - g.indptr[r]):
+        # identity, not shape: a user who overwrote the column (even with a graph of the same structure,
+        # e.g. similarity weights instead of distances) stored other row objects
+        rows = self._csr_rows.get(graph, ())
+        if len(rows) != 3:
+            return None
+        for r, obj in zip((0, g.nrows // 2, g.nrows - 1), rows):
+            if col.iloc[r] is not obj:
                 return None
         return g
 
@@ -561,9 +578,9 @@ class Prograph:
         fitness = self("Fitness").to_numpy().reshape(-1, 1)
         if scaler is not None:
             fitness = scaler().fit_transform(fitness)
-        g = self._device_graph(graph) if mode == "outdegree" else None
+        g = self._device_graph(graph) if mode in ("outdegree", "indegree") else None
         if g is not None:
-            return np.array([[g.dirichlet(fitness, boolean_weights)]])
+            return np.array([[g.dirichlet(fitness, boolean_weights, mode=mode)]])
         L = self.laplacian(graph=graph, boolean_weights=boolean_weights, mode=mode)
         return fitness.T @ L @ fitness
 

@@ -116,16 +116,21 @@ def _compact_flags(flags):
     return torch.nonzero(flags).reshape(-1).to(torch.int64)
 
 
-def _csr_row_stats(indptr, indices, weights, f=None, want=("deg",)):
+def _csr_row_stats(indptr, indices, weights, f=None, want=("deg",), row0=0, ncols=None):
     ip = indptr.numpy(); ix = indices.numpy().astype(np.int64)
     w = np.ones(len(ix)) if weights is None else weights.numpy().astype(np.float64)
     rows = np.repeat(np.arange(len(ip) - 1), np.diff(ip))
     fv = None if f is None else f.numpy().astype(np.float64)
     out = {}
     for key in want:
-        acc = np.zeros(len(ip) - 1)
-        vals = w if key == "deg" else (fv[ix] if key == "sum_f" else w * fv[ix])
-        np.add.at(acc, rows, vals)
+        if key == "col_sum":
+            acc = np.zeros(int(ncols))
+            np.add.at(acc, ix, w)
+        else:
+            acc = np.zeros(len(ip) - 1)
+            vals = {"deg": lambda: w, "sum_f": lambda: fv[ix], "sum_wf": lambda: w * fv[ix],
+                    "self_w": lambda: np.where(ix == rows + row0, w, 0.0)}[key]()
+            np.add.at(acc, rows, vals)
         out[key] = torch.from_numpy(acc)
     return out
 

@@ -129,9 +129,11 @@ def test_synthetic_sets(name):
         if key.endswith("_indptr") and not key.endswith("sub_indptr"):
             e = int(key[3:-7])
             _check_eps(g, f"eps{e}", O.build_graph(tok, eps=e))
-        if key.endswith("_idx") and key.startswith("knn") and "sub" not in key:
+        if key.endswith("_idx") and key.startswith("knn") and "sub" not in key and "sim" not in key:
             k = int(key[3:-4])
             _check_knn(g, f"knn{k}", O.build_graph(tok, k=k))
+    if "knn3_sim_idx" in g.files:
+        _check_knn(g, "knn3_sim", O.build_graph(tok, k=3, similarity=True))
     if "sub_idxs" in g.files:
         _check_eps(g, "eps2_sub", O.build_graph(tok, eps=2, idxs=g["sub_idxs"]))
         _check_knn(g, "knn3_sub", O.build_graph(tok, k=3, idxs=g["sub_idxs"]))
@@ -175,7 +177,7 @@ def test_c_oracle_matches_python_oracle():
                 ip, ix, w = C.eps_csr(tok, 0, e)
                 assert np.array_equal(ip, g[f"eps{e}_indptr"]) and np.array_equal(ix, g[f"eps{e}_indices"])
                 assert np.array_equal(w, g[f"eps{e}_weights"])
-            if key.startswith("knn") and key.endswith("_idx") and "sub" not in key:
+            if key.startswith("knn") and key.endswith("_idx") and "sub" not in key and "sim" not in key:
                 k = int(key[3:-4])
                 ix, d = C.knn(tok, k)
                 assert np.array_equal(ix, g[f"knn{k}_idx"]) and np.array_equal(d, g[f"knn{k}_w"])

@@ -206,6 +206,87 @@ def test_matrix_and_degree(pgraph):
         assert A.shape == (1000, 1000) and A.nnz == len(pgraph.get_neighbour_coords(name)[0])
     pgraph.graph["E2"] = pgraph.build_graph(eps=1)           # user overwrites the column: cache must not be used
     assert pgraph._device_graph("E2") is None and np.all(pgraph.degree("E2") == 27)
+    # ... also when the new graph has the SAME structure and only other weights (the old check
+    # compared neighbour counts of two rows and kept answering with the stale integer weights)
+    assert np.all(pgraph.degree() == 27)
+    pgraph.graph["Neighbours"] = pgraph.build_graph(eps=1, similarity=True)
+    assert pgraph._device_graph("Neighbours") is None
+    assert np.allclose(pgraph.degree(), 13.5) and np.all(pgraph.degree(boolean_weights=True) == 27)
+
+
+def _analytics_vs_reference(pg, name, g, prefix, exact_degree):
+    """degree / Laplacian diagonal / Dirichlet energy / local variance of a stored graph against the
+    values the REAL reference produced for the same graph (oracle/gen_golden.py::store_analytics,
+    prograph/prograph.py:797-946).  Tolerance: the reference keeps degrees and weights in float32 and
+    sums them in float32 (numpy pairwise for degree(), scipy's sequential column sums for the in-degree:
+    243 similarity weights of 1/3 and 1/2 drift by 1.4e-6 there), this path sums in float64 and rounds
+    once - integer weights agree exactly, similarity weights 1/(1+d) within 1e-5 relative."""
+    assert pg._device_graph(name) is not None
+    rt = 0.0 if exact_degree else 1e-5
+    for bw, tag in ((False, "w"), (True, "b")):
+        deg = pg.degree(name, boolean_weights=bw)
+        assert deg.dtype == np.float32
+        assert np.allclose(deg, g[f"{prefix}_deg_{tag}"], rtol=0.0 if bw else rt, atol=0)
+        for mode in ("outdegree", "indegree"):
+            want = g[f"{prefix}_lapdiag_{tag}_{mode[:3]}"]
+            assert np.allclose(pg.laplacian(name, boolean_weights=bw, mode=mode).diagonal(), want, rtol=max(rt, 1e-12))
+            assert np.allclose(pg.csr_graphs[name].as_csr().laplacian_diagonal(bw, mode) if hasattr(pg.csr_graphs[name], "as_csr")
+                               else pg.csr_graphs[name].laplacian_diagonal(bw, mode), want, rtol=max(rt, 1e-12))
+            got = pg.dirichlet(name, boolean_weights=bw, mode=mode)
+            assert got.shape == (1, 1)
+            assert np.allclose(got, g[f"{prefix}_dirichlet_{tag}_{mode[:3]}"], rtol=1e-9 if (exact_degree or bw) else 1e-4)
+    lv, want = pg.local_variance(name), g[f"{prefix}_locvar"]
+    assert np.array_equal(np.isnan(lv), np.isnan(want)) and np.allclose(lv[~np.isnan(lv)], want[~np.isnan(want)], rtol=1e-9, atol=1e-12)
+
+
+# ---------------------------------------------------------------- prograph/prograph.py:797-946 (SURVEY.md §8 f1)
+def test_graph_analytics_match_the_reference(pgraph):
+    g = load_golden("ref_synthetic_csv")
+    _analytics_vs_reference(pgraph, "Neighbours", g, "ana_eps1", exact_degree=True)
+    pgraph.build_graph(k=5, store="K5")
+    _analytics_vs_reference(pgraph, "K5", g, "ana_knn5", exact_degree=True)
+    pgraph.build_graph(k=4, similarity=True, store="K4s")
+    _analytics_vs_reference(pgraph, "K4s", g, "ana_knn4sim", exact_degree=False)
+    pgraph.build_graph(eps=2, similarity=True, store="E2s")
+    _analytics_vs_reference(pgraph, "E2s", g, "ana_eps2sim", exact_degree=False)
+
+
+def test_graph_analytics_with_duplicates_match_the_reference(backend, tmp_path, capsys):
+    """Exact duplicates + kNN + similarity weights: eight rows of the k=3 graph list the row itself,
+    which the reference's `L.setdiag(D)` removes from the Laplacian (prograph.py:894-896)."""
+    from prograph_amd import Prograph
+    g = load_golden("synth_n515_l20_dups")
+    f = tmp_path / "dups.csv"
+    pd.DataFrame({"Sequence": synth.tokens_to_strings(g["tokens"]), "Fitness": g["fitness"]}).to_csv(f)
+    pg = Prograph(file=str(f))
+    capsys.readouterr()
+    _analytics_vs_reference(pg, "Neighbours", g, "ana_eps1", exact_degree=True)
+    neigh = pg.build_graph(k=3, similarity=True, store="K3s")
+    idx = np.stack([a[0] for a in neigh])
+    assert np.array_equal(idx, g["knn3_sim_idx"]) and (idx == np.arange(len(idx))[:, None]).any(1).sum() == 8
+    _analytics_vs_reference(pg, "K3s", g, "ana_knn3sim", exact_degree=False)
+    pg.build_graph(k=16, store="K16")
+    _analytics_vs_reference(pg, "K16", g, "ana_knn16", exact_degree=True)
+
+
+def test_hamming_operator_cache_does_not_outlive_its_operand(backend):
+    """the operand cache was keyed on the storage address; a freed operand's
+    distances were returned for the next tensor allocated in its place."""
+    from prograph_amd.distance import hamming
+    from prograph_amd import _native
+    from oracle import prograph_oracle as O
+    dev = _native.device()
+    rng = np.random.RandomState(5)
+    Y = torch.from_numpy(rng.randint(0, 21, size=(3, 40)).astype(np.float32)).to(torch.float16).to(dev)
+    ptrs = set()
+    for it in range(6):
+        host = rng.randint(0, 21, size=(2048, 40)).astype(np.float32)
+        X = torch.from_numpy(host).to(torch.float16).to(dev)          # same shape, usually the block just freed
+        ptrs.add(X.data_ptr())
+        d = hamming(X, Y)
+        assert np.array_equal(d.cpu().numpy(), O.hamming(host.astype(np.int64), Y.cpu().numpy().astype(np.int64)).numpy()), it
+        del X, d
+    assert len(ptrs) < 6 or backend == "fake"      # the allocator did hand a block out again (what the bug needed)
 
 
 # ---------------------------------------------------------------- build_graph: reference outputs, bit-exact
@@ -318,7 +399,7 @@ def test_constructor_on_synthetic_sets(backend, name, tmp_path, capsys):
     for key in g.files:
         if key.endswith("_indptr") and "sub" not in key and key != "eps1_indptr":
             _check_tuples(pg.build_graph(eps=int(key[3:-7])), g, key[:-7])
-        if key.startswith("knn") and key.endswith("_idx") and "sub" not in key:
+        if key.startswith("knn") and key.endswith("_idx") and "sub" not in key and "sim" not in key:
             _check_tuples(pg.build_graph(k=int(key[3:-4])), g, key[:-4], knn=True)
     if "sub_idxs" in g.files:
         _check_tuples(pg.build_graph(eps=2, idxs=g["sub_idxs"]), g, "eps2_sub")
