@@ -219,7 +219,7 @@ def run_workload(name, G, rank, dev, use_dist, backend, steps, warmup, want_pcie
             indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
             weights = torch.empty(max(nnz, 1), dtype=torch.uint8, device=dev)
             _native._check(L_.pg_eps_compact_sym(*sargs, _native._ptr(indptr), _native._ptr(indices),
-                                                 _native._ptr(weights), _native._stream()), "compact_sym")
+                                                 _native._ptr(weights), 0, _native._stream()), "compact_sym")
             result["nnz"] = nnz
             result["path"] = "symmetric (every unordered pair once)"
         elif wl["mode"] == "eps":
@@ -235,7 +235,7 @@ def run_workload(name, G, rank, dev, use_dist, backend, steps, warmup, want_pcie
             args = (_native._ptr(planes.buf), planes.npad, lo, rows_local, _native._ptr(planes.buf), planes.npad, planes.n,
                     planes.g * 32, planes.bits, _native.CMP_LE, float(wl["eps"]), cap)
             _native._check(L_.pg_eps_compact(*args, _native._ptr(slot_idx), _native._ptr(slot_w), _native._ptr(counts),
-                                             _native._ptr(indptr), _native._ptr(indices), _native._ptr(weights),
+                                             _native._ptr(indptr), _native._ptr(indices), _native._ptr(weights), 0,
                                              _native._stream()), "compact")
             result["nnz"] = nnz
         else:

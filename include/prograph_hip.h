@@ -140,7 +140,7 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
 int pg_eps_compact_sym(const void *planes, int64_t npad, int64_t n, int l, int bits, int cmp, double eps, int cap,
                        const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts_up,
                        const uint32_t *counts_lo, const int64_t *indptr, int32_t *indices, uint8_t *weights,
-                       void *stream);
+                       int leave_overflow, void *stream);
 
 /*
  * pg_exclusive_scan — indptr[0..n] = exclusive prefix sum of counts[0..n) (int64).
@@ -153,15 +153,29 @@ int pg_exclusive_scan(const uint32_t *counts, int64_t n, int64_t *indptr, void *
 
 /*
  * pg_eps_compact — slots -> CSR.  indices/weights must hold indptr[nrows] entries.
- * Rows whose count exceeded `cap` are recomputed in place (same arguments as
- * pg_eps_slots).  Output: indices int32 ascending per row (the order `torch.where`
- * yields, prograph/prograph.py:736), weights uint8 = the Hamming distance.
+ * Output: indices int32 ascending per row (the order `torch.where` yields,
+ * prograph/prograph.py:736), weights uint8 = the Hamming distance.
+ * Rows whose count exceeded `cap`: leave_overflow = 0 recomputes each of them here (one wavefront per
+ * row over all columns: fine for a handful of rows); leave_overflow = 1 skips them and the caller runs
+ * pg_eps_fill_rows over the list of such rows (the engine again, exact and at engine speed however
+ * many rows overflow - dense graphs).
  */
 int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
                    const void *col_planes, int64_t col_npad, int64_t ncols,
                    int l, int bits, int cmp, double eps, int cap,
                    const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts,
-                   const int64_t *indptr, int32_t *indices, uint8_t *weights, void *stream);
+                   const int64_t *indptr, int32_t *indices, uint8_t *weights, int leave_overflow, void *stream);
+
+/*
+ * pg_eps_fill_rows — the epsilon pass for a LIST of rows, written straight into the CSR.
+ * row_list: int64[n_list] row numbers relative to row0 (ascending or not); for each the matches among
+ * all ncols columns go, in ascending column order, to indices/weights at indptr[row] (indptr as for
+ * pg_eps_compact: relative to row0; the counts that produced it are exact, so the segments fit).
+ * scratch_counts: uint32[n_list] (receives the per-row counts again).
+ */
+int pg_eps_fill_rows(const void *row_planes, int64_t row_npad, int64_t row0, const int64_t *row_list, int64_t n_list,
+                     const void *col_planes, int64_t col_npad, int64_t ncols, int l, int bits, int cmp, double eps,
+                     const int64_t *indptr, int32_t *indices, uint8_t *weights, uint32_t *scratch_counts, void *stream);
 
 /*
  * pg_knn_hamming — k nearest neighbours under the canonical (distance, index) order.

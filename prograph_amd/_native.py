@@ -28,7 +28,7 @@ SYMBOLS = [
     "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_planes_bytes",
     "pg_pack_planes",
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
-    "pg_eps_compact", "pg_eps_slots_sym", "pg_eps_compact_sym", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
+    "pg_eps_compact", "pg_eps_fill_rows", "pg_eps_slots_sym", "pg_eps_compact_sym", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
     "pg_lev_profile", "pg_lev_candidates", "pg_lev_candidates_sym", "pg_lev_knn", "pg_csr_row_stats",
 ]
 
@@ -85,9 +85,11 @@ def _load():
         lib.pg_exclusive_scan.argtypes = [_vp, _i64, _vp, _vp, _vp]
         lib.pg_eps_slots_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]
         lib.pg_eps_compact_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
-                                           _vp, _vp]
+                                           _vp, _i32, _vp]
         lib.pg_eps_compact.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
-                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]
+        lib.pg_eps_fill_rows.argtypes = [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl,
+                                         _vp, _vp, _vp, _vp, _vp]
         lib.pg_knn_hamming.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
         lib.pg_knn_hamming_round.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp,
                                              _vp, _vp]
@@ -247,11 +249,11 @@ def eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
     """
     Epsilon-neighbourhood CSR of rows [row0, row0+nrows) of `rp` against all of `cp`.
     Returns device tensors (indptr int64 [nrows+1], indices int32 [nnz], weights uint8 [nnz]).
-    One host sync (reading nnz and the overflow statistics) sits between the N^2 pass and the
-    compaction.  Rows with more matches than `cap` stay exact (the compaction kernel recomputes
-    them), but a recomputed row costs a full sweep by one wave: when more than 2 % of the rows
-    overflow, the N^2 pass is repeated once with a capacity that covers 99.5 % of the rows
-    (bounded by PG_SLOT_BYTES_MAX, default 4 GiB of slots).
+    ONE host sync (nnz and the number of rows that outgrew their slot) sits between the N^2 pass and
+    the compaction: the output size is data dependent.  Rows with more matches than `cap` stay exact:
+    a handful is recomputed inside the compaction kernel; more than that (dense graphs - most rows of
+    a mutant library at eps >= 2) are listed on the device and the engine runs once more over just those
+    rows, writing straight into the CSR (`pg_eps_fill_rows`).
     """
     L = lib()
     nrows = rp.n - row0 if nrows is None else int(nrows)
@@ -265,39 +267,38 @@ def eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
     counts_lo = torch.empty(nrows, dtype=torch.int32, device=dev) if sym else None
     indptr = torch.empty(nrows + 1, dtype=torch.int64, device=dev)
     scratch = torch.empty(int(L.pg_scan_scratch_bytes(nrows)), dtype=torch.uint8, device=dev)
-    budget = int(os.environ.get("PG_SLOT_BYTES_MAX", str(4 << 30)))
-    for attempt in (0, 1):
-        slot_idx = torch.empty(nrows * cap, dtype=torch.int32, device=dev)
-        slot_w = torch.empty(nrows * cap, dtype=torch.uint8, device=dev)
-        if sym:
-            args = (_ptr(rp.buf), rp.npad, rp.n, rp.g * 32, bits, cmp, float(eps), cap, _ptr(slot_idx), _ptr(slot_w),
-                    _ptr(counts), _ptr(counts_lo))
-            _check(L.pg_eps_slots_sym(*args, _stream()), "pg_eps_slots_sym")
-            total = counts + counts_lo
-        else:
-            args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, bits, cmp, float(eps),
-                    cap, _ptr(slot_idx), _ptr(slot_w), _ptr(counts))
-            _check(L.pg_eps_slots(*args, _stream()), "pg_eps_slots")
-            total = counts
-        _check(L.pg_exclusive_scan(_ptr(total), nrows, _ptr(indptr), _ptr(scratch), _stream()), "pg_exclusive_scan")
+    slot_idx = torch.empty(nrows * cap, dtype=torch.int32, device=dev)
+    slot_w = torch.empty(nrows * cap, dtype=torch.uint8, device=dev)
+    if sym:
+        args = (_ptr(rp.buf), rp.npad, rp.n, rp.g * 32, bits, cmp, float(eps), cap, _ptr(slot_idx), _ptr(slot_w),
+                _ptr(counts), _ptr(counts_lo))
+        _check(L.pg_eps_slots_sym(*args, _stream()), "pg_eps_slots_sym")
+        total = counts + counts_lo
+        over = (total > cap) | (counts_lo > 512)              # more than PG_SORT_MAX entries from below: not rank-sorted in LDS
+    else:
+        args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, bits, cmp, float(eps),
+                cap, _ptr(slot_idx), _ptr(slot_w), _ptr(counts))
+        _check(L.pg_eps_slots(*args, _stream()), "pg_eps_slots")
+        total = counts
         over = total > cap
-        stats = torch.stack([indptr[-1], over.sum(), total.max().to(torch.int64)]).cpu()     # the one sync
-        nnz, n_over, mx = (int(v) for v in stats)
-        if attempt == 0 and n_over * 50 > nrows:
-            q = int(torch.kthvalue(total, max(1, int(0.995 * nrows))).values.item())
-            cap2 = min((max(q, 2 * cap) + 63) // 64 * 64, (mx + 63) // 64 * 64, max(cap, budget // (5 * nrows)))
-            if cap2 > cap:
-                cap = cap2
-                del slot_idx, slot_w
-                continue
-        break
+    _check(L.pg_exclusive_scan(_ptr(total), nrows, _ptr(indptr), _ptr(scratch), _stream()), "pg_exclusive_scan")
+    nnz, n_over = (int(v) for v in torch.stack([indptr[-1], over.sum()]).cpu())     # the one sync
     indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
     weights = torch.empty(max(nnz, 1), dtype=torch.uint8, device=dev)[:nnz]
     if nnz:
+        fill = n_over > int(os.environ.get("PG_FILL_MIN_ROWS", "8"))
         if sym:
-            _check(L.pg_eps_compact_sym(*args, _ptr(indptr), _ptr(indices), _ptr(weights), _stream()), "pg_eps_compact_sym")
+            _check(L.pg_eps_compact_sym(*args, _ptr(indptr), _ptr(indices), _ptr(weights), 1 if fill else 0, _stream()),
+                   "pg_eps_compact_sym")
         else:
-            _check(L.pg_eps_compact(*args, _ptr(indptr), _ptr(indices), _ptr(weights), _stream()), "pg_eps_compact")
+            _check(L.pg_eps_compact(*args, _ptr(indptr), _ptr(indices), _ptr(weights), 1 if fill else 0, _stream()),
+                   "pg_eps_compact")
+        if fill:
+            rows = compact_flags(over.to(torch.uint8), count=n_over)
+            again = torch.empty(n_over, dtype=torch.int32, device=dev)
+            _check(L.pg_eps_fill_rows(_ptr(rp.buf), rp.npad, row0, _ptr(rows), n_over, _ptr(cp.buf), cp.npad, cp.n,
+                                      cp.g * 32, bits, cmp, float(eps), _ptr(indptr), _ptr(indices), _ptr(weights),
+                                      _ptr(again), _stream()), "pg_eps_fill_rows")
     return indptr, indices, weights
 
 
@@ -389,8 +390,9 @@ def position_bitmask(positions, g):
     return out
 
 
-def compact_flags(flags):
-    """Ascending int64 indices of the non-zero entries of a uint8 device vector."""
+def compact_flags(flags, count=None):
+    """Ascending int64 indices of the non-zero entries of a uint8 device vector.  `count`: the number
+    of non-zero entries when the caller already knows it (saves the host sync that reads it)."""
     L = lib()
     n = flags.numel()
     dev = flags.device
@@ -398,7 +400,7 @@ def compact_flags(flags):
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     scratch = torch.empty(int(L.pg_scan_scratch_bytes(n)), dtype=torch.uint8, device=dev)
     _check(L.pg_compact_flags(_ptr(flags), n, _ptr(out), _ptr(cnt), _ptr(scratch), _stream()), "pg_compact_flags")
-    return out[: int(cnt.item())]
+    return out[: int(cnt.item()) if count is None else int(count)]
 
 
 def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats=False):

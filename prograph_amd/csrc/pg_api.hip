@@ -572,8 +572,9 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
 int pg_eps_compact_sym(const void *planes, int64_t npad, int64_t n, int l, int bits, int cmp, double eps, int cap,
                        const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts_up,
                        const uint32_t *counts_lo, const int64_t *indptr, int32_t *indices, uint8_t *weights,
-                       void *stream) {
+                       int leave_overflow, void *stream) {
   CompactParams c;
+  c.skipOverflow = leave_overflow ? 1 : 0;
   if (int rc = fill_nsq(&c.e, planes, npad, 0, n, planes, npad, n, l, bits)) return rc;
   if (!slot_idx || !slot_w || !counts_up || !counts_lo || !indptr || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
     return fail(PG_E_BADARG, "pg_eps_compact_sym: bad argument");
@@ -607,8 +608,9 @@ int pg_exclusive_scan(const uint32_t *counts, int64_t n, int64_t *indptr, void *
 int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
                    int64_t col_npad, int64_t ncols, int l, int bits, int cmp, double eps, int cap,
                    const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts, const int64_t *indptr,
-                   int32_t *indices, uint8_t *weights, void *stream) {
+                   int32_t *indices, uint8_t *weights, int leave_overflow, void *stream) {
   CompactParams c;
+  c.skipOverflow = leave_overflow ? 1 : 0;
   if (int rc = fill_nsq(&c.e, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits)) return rc;
   if (!slot_idx || !slot_w || !counts || !indptr || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
     return fail(PG_E_BADARG, "pg_eps_compact: bad argument");
@@ -620,6 +622,27 @@ int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64
   c.e.counts = const_cast<u32 *>(counts);
   c.indptr = (const long long *)indptr; c.indices = indices; c.weights = weights;
   return launched(kCompact[pg_ngroups(l) - 1](bits, c, (hipStream_t)stream), "pg_compact_kernel");
+}
+
+// Rows whose matches did not fit their slot: the all-pairs engine runs once more over just those rows
+// (row_list, relative to row0) and writes their matches, in column order, straight into the CSR at
+// indptr[row] - exact for any slot capacity, at engine speed however many rows overflow.
+int pg_eps_fill_rows(const void *row_planes, int64_t row_npad, int64_t row0, const int64_t *row_list, int64_t n_list,
+                     const void *col_planes, int64_t col_npad, int64_t ncols, int l, int bits, int cmp, double eps,
+                     const int64_t *indptr, int32_t *indices, uint8_t *weights, uint32_t *scratch_counts, void *stream) {
+  NsqParams p;
+  if (!row_list || n_list <= 0) return fail(PG_E_BADARG, "pg_eps_fill_rows: bad argument");
+  if (int rc = fill_nsq(&p, row_planes, row_npad, row0, n_list, col_planes, col_npad, ncols, l, bits)) return rc;
+  if (!indptr || !indices || !weights || !scratch_counts || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
+    return fail(PG_E_BADARG, "pg_eps_fill_rows: bad argument");
+  eps_interval(cmp, eps, &p.lo, &p.span);
+  p.hi1 = (p.lo > 0xFFFFFF00u - 1u) ? 0u : p.lo + p.span + 1u;
+  p.cap = 0xFFFFFFFFu;                                     // a row's place in the CSR holds all of its matches
+  p.rowList = (const long long *)row_list; p.fillIndptr = (const long long *)indptr;
+  p.slotIdx = indices; p.slotW = weights; p.counts = scratch_counts;
+  int grid = 0;
+  plan_mm(n_list, &p, &grid);
+  return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps fill)");
 }
 
 static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,

@@ -214,6 +214,9 @@ __device__ __forceinline__ u32 wave_shr1(u32 v, u32 fill) {
 struct NsqParams {
   const uint4 *rowPlanes;
   long long rowNpad, row0, nrows;
+  // pg_mm.h, eps fill pass (pg_eps_fill_rows): the i-th row of the launch is row rowList[i] (relative to
+  // row0) and its matches go straight to the CSR at fillIndptr[rowList[i]] (slotIdx/slotW = indices/weights)
+  const long long *rowList, *fillIndptr;
   const uint4 *colPlanes;
   long long colNpad, ncols;
   unsigned long long *stats;   // debug builds (-DPG_MM_STATS): event counters of pg_mm_kernel, else unused
@@ -252,6 +255,7 @@ struct DenseParams {
 
 struct CompactParams {
   NsqParams e;
+  int skipOverflow;   // 1: rows beyond their slot are left to pg_eps_fill_rows instead of being recomputed here
   const long long *indptr;
   int *indices;
   unsigned char *weights;

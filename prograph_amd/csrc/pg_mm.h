@@ -131,9 +131,20 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
     for (int e = lane; e < RB * Q; e += 64) {
       const int rr = e % RB, q = e / RB;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (rr < nr) v = p.rowPlanes[(long long)q * p.rowNpad + p.row0 + pr0 + rr];
+      if (rr < nr) v = p.rowPlanes[(long long)q * p.rowNpad + p.row0 + (p.rowList ? p.rowList[pr0 + rr] : pr0 + rr)];
       rowbuf[wv][rr][q] = v;
     }
+    // eps: where row `lane` of the pass stores its matches: its slot, or (fill pass) its place in the CSR
+    u32 baselo = 0, basehi = 0;
+    if constexpr (kEps) {
+      long long b = 0;
+      if (lane < nr) b = p.fillIndptr ? p.fillIndptr[p.rowList ? p.rowList[pr0 + lane] : pr0 + lane] : (pr0 + lane) * (long long)p.cap;
+      baselo = (u32)b;
+      basehi = (u32)((unsigned long long)b >> 32);
+    }
+    auto row_base = [&](int row) -> long long {
+      return (long long)(((unsigned long long)__builtin_amdgcn_readlane(basehi, row) << 32) | __builtin_amdgcn_readlane(baselo, row));
+    };
     const u32 G0 = (MODE == PG_MODE_KNN && canFilter) ? p.knnGuess : 0u;
     u32 failed = 0;                                         // kNN: rows that lost their optimistic cap (bit = row, all 32 bits in use)
     u32 resweep = 0;                                        // kNN: 1 in phase 1 (early super-tiles again for the failed rows)
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
           const u32 pos = cnt + mask_rank(m2);
           const u32 posb = emit_lower(h2, (u32)(pr0 + rr), col, d + p.lo);
           if (h2 && pos < p.cap) {
-            const long long o = (pr0 + rr) * (long long)p.cap + pos;
+            const long long o = row_base(rr) + pos;
             p.slotIdx[o] = (int)col;
             p.slotW[o] = (unsigned char)(d + p.lo);
             if constexpr (kSym) {
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p)
           const u32 cnt = __builtin_amdgcn_readlane(cntv, (int)row);
           const u32 pos = cnt + mask_rank(same);
           if (mine && pos < p.cap) {
-            const long long o = (pr0 + row) * (long long)p.cap + pos;
+            const long long o = row_base((int)row) + pos;
             p.slotIdx[o] = (int)col;
             p.slotW[o] = (unsigned char)(d + p.lo);
             if constexpr (kSym) {

@@ -669,6 +669,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_compact_kernel(const Compact
     }
     return;
   }
+  if (p.skipOverflow) return;                             // pg_eps_fill_rows takes these rows (all of them at engine speed)
   uint4 r[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) r[q] = p.e.rowPlanes[(long long)q * p.e.rowNpad + p.e.row0 + row];

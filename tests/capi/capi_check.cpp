@@ -85,8 +85,8 @@ int main(int argc, char **argv) {
     if (memcmp(ptr.data(), rptr.data(), (n + 1) * 8)) { fprintf(stderr, "eps indptr differs (sym=%d)\n", sym); return 6; }
     int32_t *d_ind = dmalloc<int32_t>(rnnz);
     uint8_t *d_w = dmalloc<uint8_t>(rnnz);
-    if (sym) PG(pg_eps_compact_sym(d_planes, npad, n, l, PG_BITS_5, PG_CMP_LE, eps, cap, d_sidx, d_sw, d_cnt, d_lo, d_ptr, d_ind, d_w, nullptr));
-    else PG(pg_eps_compact(d_planes, npad, 0, n, d_planes, npad, n, l, PG_BITS_5, PG_CMP_LE, eps, cap, d_sidx, d_sw, d_cnt, d_ptr, d_ind, d_w, nullptr));
+    if (sym) PG(pg_eps_compact_sym(d_planes, npad, n, l, PG_BITS_5, PG_CMP_LE, eps, cap, d_sidx, d_sw, d_cnt, d_lo, d_ptr, d_ind, d_w, 0, nullptr));
+    else PG(pg_eps_compact(d_planes, npad, 0, n, d_planes, npad, n, l, PG_BITS_5, PG_CMP_LE, eps, cap, d_sidx, d_sw, d_cnt, d_ptr, d_ind, d_w, 0, nullptr));
     std::vector<int32_t> ind(rnnz ? rnnz : 1);
     std::vector<uint8_t> w(rnnz ? rnnz : 1);
     HIP(hipMemcpy(ind.data(), d_ind, rnnz * 4, hipMemcpyDeviceToHost));

@@ -20,6 +20,14 @@ SETS = ["ref_synthetic_csv", "synth_n1000_l32", "synth_n2085_l64", "synth_n515_l
 BITS = [5, 8]
 
 
+@pytest.fixture(autouse=True, params=["valu", "mfma"])
+def engine(request, monkeypatch):
+    """Every test runs on both all-pairs engines: pg_nsq.h (stage 1 on the VALU) and pg_mm.h (stage 1 on
+    the matrix cores).  Left alone the library picks by size (MFMA from 65 536 rows on)."""
+    monkeypatch.setenv("PG_ENGINE", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def nat():
     from prograph_amd import _native
@@ -652,3 +660,49 @@ def test_knn_beyond_63_neighbours(nat):
     ridx, rd = C.knn(small, 130)
     assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
     assert np.all(idx.cpu().numpy()[:, 89:] == -1)
+
+
+@pytest.mark.parametrize("case", ["knn", "eps1", "eps2"])
+def test_dense_mutant_library_is_exact(nat, engine, case):
+    """
+    DENSE data - one cluster, a mutant library around one seed, every pair within 6 substitutions (what
+    prograph is used on; the reference's own data/synthetic_data.csv is of this kind) - at full size,
+    against the C oracle on row windows.  kNN k=16 at N = 200 000 (BASELINE configs[2]'s shape) and the
+    epsilon graphs at N = 50 000: eps <= 1 (the constructor's default graph) and eps <= 2, where most
+    rows outgrow any slot and the engine's fill pass (pg_eps_fill_rows) writes the CSR.
+    """
+    import time
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    if case == "knn":
+        N, L, k = 200_000, 64, 16
+        tok = synth.clustered_tokens(N, L, members=N)
+        p = nat.pack(torch.from_numpy(tok), bits=5)
+        nat.knn_graph(p, p, k); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kidx, kd = nat.knn_graph(p, p, k)
+        torch.cuda.synchronize()
+        print(f"\ndense kNN k=16 N={N} L={L} [{engine}]: {(time.perf_counter() - t0) * 1e3:.2f} ms")
+        kidx, kd = kidx.cpu().numpy(), kd.cpu().numpy()
+        for r0 in (0, 77_777, N - 48):
+            ri, rd = C.knn(tok, k, row0=r0, nrows=48)
+            assert np.array_equal(kidx[r0:r0 + 48], ri) and np.array_equal(kd[r0:r0 + 48], rd), r0
+        return
+    N, L, eps = 50_000, 64, (1 if case == "eps1" else 2)
+    tok = synth.clustered_tokens(N, L, members=N)
+    p = nat.pack(torch.from_numpy(tok), bits=5)
+    nat.eps_graph(p, p, nat.CMP_LE, eps); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    indptr, idx, w = nat.eps_graph(p, p, nat.CMP_LE, eps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) * 1e3
+    indptr = indptr.cpu().numpy()
+    print(f"\ndense eps<={eps} N={N} L={L} [{engine}]: {dt:.2f} ms, nnz {int(indptr[-1])}, max degree {int(np.diff(indptr).max())}")
+    for r0 in (0, 31_111, N - 40):
+        ip, ix, ww = C.eps_csr(tok, 0, eps, row0=r0, nrows=40)
+        a, b = int(indptr[r0]), int(indptr[r0 + 40])
+        assert np.array_equal(indptr[r0:r0 + 41] - indptr[r0], ip), r0
+        assert np.array_equal(idx[a:b].cpu().numpy(), ix) and np.array_equal(w[a:b].cpu().numpy(), ww), r0
+    # symmetry of the whole graph through degrees: in-degree == out-degree for a symmetric relation
+    indeg = torch.bincount(idx.to(torch.int64), minlength=N).cpu().numpy()
+    assert np.array_equal(indeg, np.diff(indptr))
