@@ -48,6 +48,7 @@ extern "C" {
 #define PG_E_TOOLONG  (-2)   /* L > PG_MAX_L (PG_MAX_L_5BIT with 5 bit planes)          */
 #define PG_E_TOOMANY  (-3)   /* N > PG_MAX_N_KNN (24-bit column index in packed keys)   */
 #define PG_E_NODEV    (-4)   /* no HIP device / wrong architecture                      */
+#define PG_E_COMM     (-5)   /* RCCL missing or a collective failed (pg_last_error)     */
 
 #define PG_MAX_L      128          /* tokens per sequence, 8 bit planes                  */
 #define PG_MAX_L_5BIT 255          /* tokens per sequence, 5 bit planes (distance fits uint8) */
@@ -277,6 +278,26 @@ int pg_csr_row_stats(const int64_t *indptr, const int32_t *indices, const uint8_
  */
 int pg_compact_flags(const uint8_t *flags, int64_t n, int64_t *out_idx, int64_t *out_count,
                      void *scratch, void *stream);
+
+/*
+ * Multi-GPU: the path's ONE collective (e).  The N^2 pair space shards row-block
+ * wise, one process per GPU; every rank needs the whole token matrix, so the ranks all-gather their
+ * row shards once (RCCL over xGMI: 64 MB at N = 1M, L = 64) and never talk again.  The reference has
+ * no counterpart (single hard-coded cuda:0, prograph/prograph.py:726).
+ *   pg_comm_unique_id   rank 0 creates the 128-byte id (ncclGetUniqueId); the host carries it to the
+ *                       other ranks by its own means (MPI, a file, torch.distributed's store, ...)
+ *   pg_comm_init        every rank, on its GPU (the current HIP device): ncclCommInitRank
+ *   pg_allgather_tokens shard (rows_per_rank, l) uint8, contiguous, the same rows_per_rank on every
+ *                       rank (pad the last block with zero rows); full (nranks*rows_per_rank, l);
+ *                       enqueued on `stream`, no host synchronisation
+ * RCCL is resolved at run time (the copy the host process already loaded, else the ROCm installation's):
+ * a host without librccl.so still loads this library and gets PG_E_COMM from these four calls only.
+ */
+#define PG_COMM_ID_BYTES 128
+int pg_comm_unique_id(void *id128);
+int pg_comm_init(void **comm, int nranks, int rank, const void *id128);
+int pg_comm_destroy(void *comm);
+int pg_allgather_tokens(void *comm, const void *shard, int64_t rows_per_rank, int l, void *full, void *stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ SYMBOLS = [
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
     "pg_eps_compact", "pg_eps_fill_rows", "pg_eps_slots_sym", "pg_eps_compact_sym", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
     "pg_lev_profile", "pg_lev_candidates", "pg_lev_candidates_sym", "pg_lev_knn", "pg_csr_row_stats",
+    "pg_comm_unique_id", "pg_comm_init", "pg_comm_destroy", "pg_allgather_tokens",
 ]
 
 
@@ -101,6 +102,10 @@ def _load():
         lib.pg_lev_candidates_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_lev_knn.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp]
+        lib.pg_comm_unique_id.argtypes = [_vp]
+        lib.pg_comm_init.argtypes = [ctypes.POINTER(_vp), _i32, _i32, _vp]
+        lib.pg_comm_destroy.argtypes = [_vp]
+        lib.pg_allgather_tokens.argtypes = [_vp, _vp, _i64, _i32, _vp, _vp]
         for name in SYMBOLS:
             fn = getattr(lib, name)
             if fn.restype is ctypes.c_int and name not in ("pg_version",):
@@ -481,6 +486,38 @@ def csr_row_stats(indptr, indices, weights, f=None, want=("deg",), row0=0, ncols
                                   _ptr(out.get("deg")), _ptr(out.get("sum_f")), _ptr(out.get("sum_wf")),
                                   _ptr(out.get("self_w")), _ptr(out.get("col_sum")), _stream()), "pg_csr_row_stats")
     return out
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 creates it, the host carries it to the other ranks)."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().pg_comm_unique_id(buf), "pg_comm_unique_id")
+    return buf.raw
+
+
+def comm_init(nranks, rank, id_bytes):
+    """RCCL communicator of this rank on the current HIP device; returns an opaque handle."""
+    device()
+    h = _vp(0)
+    _check(lib().pg_comm_init(ctypes.byref(h), int(nranks), int(rank), ctypes.c_char_p(bytes(id_bytes))), "pg_comm_init")
+    return h
+
+
+def comm_destroy(comm):
+    _check(lib().pg_comm_destroy(comm), "pg_comm_destroy")
+
+
+def allgather_tokens(comm, shard, nranks):
+    """(rows_per_rank, L) uint8 device shard of every rank -> (nranks*rows_per_rank, L) on every rank."""
+    if shard.dtype != torch.uint8 or shard.dim() != 2 or not shard.is_cuda:
+        raise TypeError("allgather_tokens expects a 2-D uint8 device tensor")
+    shard = shard.contiguous()
+    full = torch.empty((shard.shape[0] * int(nranks), shard.shape[1]), dtype=torch.uint8, device=shard.device)
+    _check(lib().pg_allgather_tokens(comm, _ptr(shard), shard.shape[0], shard.shape[1], _ptr(full), _stream()), "pg_allgather_tokens")
+    return full
 
 
 def device_info():

@@ -4,7 +4,9 @@
 #include "pg_mm.h"
 #include "../../include/prograph_hip.h"
 
+#include <dlfcn.h>
 #include <math.h>
+#include <rccl/rccl.h>   // types only: the library is resolved at run time (dlopen), there is no link dependency
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -801,6 +803,83 @@ int pg_compact_flags(const uint8_t *flags, int64_t n, int64_t *out_idx, int64_t 
   pg_scan_apply<unsigned char, 1><<<dim3((unsigned)nb), dim3(256), 0, s>>>(flags, n, part, nb, (long long *)out_idx,
                                                                           (long long *)out_count);
   return launched((int)hipGetLastError(), "pg_compact_flags");
+}
+
+// ---------------------------------------------------------------------------------------
+// The path's one collective: all-gather of the row shards of the token matrix (e).
+// RCCL is bound at run time: the copy the host process already carries (torch ships one as
+// "librccl.so") or the ROCm installation's.  One communicator = one rank = one GPU (the current HIP
+// device at pg_comm_init); the 128-byte id travels between the ranks by whatever channel the host has.
+// ---------------------------------------------------------------------------------------
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+  const char *(*GetErrorString)(ncclResult_t);
+};
+static RcclApi *rccl() {
+  static RcclApi api;
+  static int state = 0;   // 0 untried, 1 ok, -1 missing
+  if (state == 0) {
+    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);           // the host's copy, if it has one loaded
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h) {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+      api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+    }
+    state = (h && api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather) ? 1 : -1;
+  }
+  return state == 1 ? &api : nullptr;
+}
+static int rcclfail(RcclApi *r, ncclResult_t e, const char *where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, r->GetErrorString ? r->GetErrorString(e) : "RCCL error");
+  return PG_E_COMM;
+}
+
+int pg_comm_unique_id(void *id128) {
+  RcclApi *r = rccl();
+  if (!r) return fail(PG_E_COMM, "pg_comm_unique_id: librccl.so not found");
+  if (!id128) return fail(PG_E_BADARG, "pg_comm_unique_id: bad argument");
+  ncclUniqueId id;
+  ncclResult_t e = r->GetUniqueId(&id);
+  if (e != ncclSuccess) return rcclfail(r, e, "ncclGetUniqueId");
+  static_assert(sizeof(id) == PG_COMM_ID_BYTES, "ncclUniqueId size");
+  memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+int pg_comm_init(void **comm, int nranks, int rank, const void *id128) {
+  RcclApi *r = rccl();
+  if (!r) return fail(PG_E_COMM, "pg_comm_init: librccl.so not found");
+  if (!comm || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(PG_E_BADARG, "pg_comm_init: bad argument");
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t c = nullptr;
+  ncclResult_t e = r->CommInitRank(&c, nranks, id, rank);
+  if (e != ncclSuccess) return rcclfail(r, e, "ncclCommInitRank");
+  *comm = (void *)c;
+  return 0;
+}
+
+int pg_comm_destroy(void *comm) {
+  RcclApi *r = rccl();
+  if (!r || !comm) return fail(PG_E_BADARG, "pg_comm_destroy: bad argument");
+  ncclResult_t e = r->CommDestroy((ncclComm_t)comm);
+  return e == ncclSuccess ? 0 : rcclfail(r, e, "ncclCommDestroy");
+}
+
+int pg_allgather_tokens(void *comm, const void *shard, int64_t rows_per_rank, int l, void *full, void *stream) {
+  RcclApi *r = rccl();
+  if (!r) return fail(PG_E_COMM, "pg_allgather_tokens: librccl.so not found");
+  if (!comm || !shard || !full || rows_per_rank <= 0 || l <= 0) return fail(PG_E_BADARG, "pg_allgather_tokens: bad argument");
+  ncclResult_t e = r->AllGather(shard, full, (size_t)rows_per_rank * (size_t)l, ncclUint8, (ncclComm_t)comm, (hipStream_t)stream);
+  return e == ncclSuccess ? 0 : rcclfail(r, e, "ncclAllGather");
 }
 
 }  // extern "C"

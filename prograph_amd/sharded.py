@@ -9,8 +9,11 @@ gives every GPU the full (N, L) matrix (64 MB at N = 1M, L = 64), and after that
 talks to another: each computes `rows_local x N` pairs and keeps its CSR / kNN slice with
 GLOBAL column indices.  Concatenating the slices in rank order is the single-GPU result.
 
-Everything here is host logic + `torch.distributed` plumbing; the compute entry points are the
-same C-ABI calls as the single-GPU path (prograph_amd/_native.py).
+Everything here is host logic.  The all-gather itself is a C-ABI call (`pg_allgather_tokens`: RCCL
+bound inside libprograph_hip.so); `torch.distributed` only carries the 128-byte communicator id
+between the ranks once (any backend) and serves the CPU rehearsal of the partitioning (gloo, tensors
+on the host: tests/test_sharded_gloo.py).  The compute entry points are the same C-ABI calls as the
+single-GPU path (prograph_amd/_native.py).
 """
 import numpy as np
 import torch
@@ -31,23 +34,43 @@ def shard_rows(n, world):
     return [row_block(n, world, r) for r in range(world)]
 
 
+_COMMS = {}     # (world, rank, device index) -> RCCL communicator handle of this process
+
+
+def _comm(world, rank, dev, group=None):
+    """This rank's RCCL communicator (created once): rank 0 makes the id, torch.distributed's
+    object broadcast carries the 128 bytes - the only use of torch.distributed on the GPU data path."""
+    key = (world, rank, dev.index)
+    if key not in _COMMS:
+        box = [_native.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        with torch.cuda.device(dev):
+            _COMMS[key] = _native.comm_init(world, rank, box[0])
+    return _COMMS[key]
+
+
 def allgather_tokens(local_tokens, n_total, group=None):
     """
     Gather the (rows_r, L) uint8 shards of all ranks into the full (n_total, L) matrix on every
-    rank with one `all_gather_into_tensor` (the last rank's block may be short: shards are
-    zero-padded to ceil(n/world) rows for the collective and the tail is dropped afterwards).
+    rank with ONE all-gather (the last rank's block may be short: shards are zero-padded to
+    ceil(n/world) rows for the collective and the tail is dropped afterwards).  Device shards go
+    through `pg_allgather_tokens` (RCCL over xGMI inside the C-ABI library); host tensors (the CPU
+    rehearsal) and the several-ranks-on-one-GPU rehearsal (PG_DIST_BACKEND=gloo) use torch's gloo.
     """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
     if not dist.is_initialized():
         return local_tokens[:n_total]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     per = -(-int(n_total) // world)
     L = local_tokens.shape[1]
     if local_tokens.shape[0] != per:
         padded = torch.zeros((per, L), dtype=local_tokens.dtype, device=local_tokens.device)
         padded[: local_tokens.shape[0]] = local_tokens
         local_tokens = padded
+    if local_tokens.is_cuda and dist.get_backend(group) != "gloo":
+        return _native.allgather_tokens(_comm(world, rank, local_tokens.device, group), local_tokens, world)[:n_total]
     full = torch.empty((per * world, L), dtype=local_tokens.dtype, device=local_tokens.device)
-    if dist.get_backend(group) == "gloo" and local_tokens.is_cuda:
+    if local_tokens.is_cuda:
         # rehearsal mode (several ranks sharing one GPU, CPU collectives): stage through the host
         host = torch.empty((per * world, L), dtype=local_tokens.dtype)
         dist.all_gather_into_tensor(host, local_tokens.cpu().contiguous(), group=group)

@@ -42,6 +42,22 @@ int main(int argc, char **argv) {
   HIP(hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost));
   if (flag) { fprintf(stderr, "pack flagged a token\n"); return 4; }
 
+  // ---- the path's collective through the C ABI: a one-rank RCCL communicator gathers the shard onto itself
+  {
+    unsigned char id[PG_COMM_ID_BYTES];
+    void *comm = nullptr;
+    PG(pg_comm_unique_id(id));
+    PG(pg_comm_init(&comm, 1, 0, id));
+    uint8_t *d_full = dmalloc<uint8_t>((size_t)n * l);
+    PG(pg_allgather_tokens(comm, d_tok, n, l, d_full, nullptr));
+    HIP(hipDeviceSynchronize());
+    std::vector<uint8_t> back((size_t)n * l);
+    HIP(hipMemcpy(back.data(), d_full, (size_t)n * l, hipMemcpyDeviceToHost));
+    if (memcmp(back.data(), tok.data(), (size_t)n * l)) { fprintf(stderr, "pg_allgather_tokens: gathered matrix differs\n"); return 9; }
+    PG(pg_comm_destroy(comm));
+    printf("pg_allgather_tokens (RCCL, 1 rank): %lld x %d tokens gathered, identical\n", (long long)n, l);
+  }
+
   // ---- kNN
   int32_t *d_idx = dmalloc<int32_t>((size_t)n * k);
   uint8_t *d_dist = dmalloc<uint8_t>((size_t)n * k);

@@ -706,3 +706,16 @@ def test_dense_mutant_library_is_exact(nat, engine, case):
     # symmetry of the whole graph through degrees: in-degree == out-degree for a symmetric relation
     indeg = torch.bincount(idx.to(torch.int64), minlength=N).cpu().numpy()
     assert np.array_equal(indeg, np.diff(indptr))
+
+
+def test_allgather_tokens_through_the_c_abi(nat):
+    """pg_comm_* / pg_allgather_tokens: RCCL bound inside the library, no torch.distributed on the data path.
+    One rank (this box has one GPU): the gather of a padded shard must reproduce it."""
+    comm = nat.comm_init(1, 0, nat.comm_unique_id())
+    try:
+        tok = torch.randint(0, 21, (12_345, 64), dtype=torch.uint8, device=nat.device())
+        full = nat.allgather_tokens(comm, tok, 1)
+        torch.cuda.synchronize()
+        assert full.shape == tok.shape and torch.equal(full, tok)
+    finally:
+        nat.comm_destroy(comm)
