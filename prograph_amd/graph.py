@@ -145,3 +145,43 @@ class KNNGraph:
             torch.zeros(n + 1, dtype=torch.int64, device=self.idx.device)
         return CSRGraph(indptr, self.idx[:, :kk].reshape(-1).contiguous(), self.dist[:, :kk].reshape(-1).contiguous(),
                         self.ncols, similarity=self.similarity, row0=self.row0)
+
+
+# ----------------------------------------------------------------------------------------------
+# Persistence of device graphs without per-row Python objects.  The reference
+# pickles the DataFrame, `Neighbours` column of N tuples included (prograph/utils/save.py:5-39);
+# at N = 1M that is a million small arrays.  A graph is three flat arrays: they go into one .npz.
+# ----------------------------------------------------------------------------------------------
+def save_graphs(path, graphs):
+    """{name: CSRGraph | KNNGraph} -> one .npz (arrays `<name>/indptr|indices|weights` or `<name>/idx|dist`
+    plus a small meta vector [kind, ncols, similarity, row0])."""
+    out = {}
+    for name, g in graphs.items():
+        if isinstance(g, KNNGraph):
+            out[f"{name}/idx"] = g.idx.cpu().numpy()
+            out[f"{name}/dist"] = g.dist.cpu().numpy()
+            out[f"{name}/meta"] = np.array([1, g.ncols, int(g.similarity), g.row0], dtype=np.int64)
+        else:
+            out[f"{name}/indptr"] = g.indptr.cpu().numpy()
+            out[f"{name}/indices"] = g.indices.cpu().numpy()
+            out[f"{name}/weights"] = g.weights.cpu().numpy()
+            out[f"{name}/meta"] = np.array([0, g.ncols, int(g.similarity), g.row0], dtype=np.int64)
+    np.savez(path, **out)
+
+
+def load_graphs(path, device=None):
+    """Inverse of save_graphs (no pickled objects inside: plain arrays, `allow_pickle=False`)."""
+    device = _native.device() if device is None else device
+    z = np.load(path, allow_pickle=False)
+    graphs = {}
+    for key in z.files:
+        if not key.endswith("/meta"):
+            continue
+        name = key[:-5]
+        kind, ncols, sim, row0 = (int(v) for v in z[key])
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(z[f"{name}/{a}"])).to(device)
+        if kind == 1:
+            graphs[name] = KNNGraph(t("idx"), t("dist"), ncols, similarity=bool(sim), row0=row0)
+        else:
+            graphs[name] = CSRGraph(t("indptr"), t("indices"), t("weights"), ncols, similarity=bool(sim), row0=row0)
+    return graphs

@@ -26,6 +26,7 @@ and returns ranks 1..k.  Weights are bit-identical to the reference either way.
 """
 import copy
 import operator
+import os
 
 import numpy as np
 import pandas as pd
@@ -78,6 +79,8 @@ class Prograph:
 
         if "Tokenized" not in self.graph:
             self.graph["Tokenized"] = list(self.tokenized)
+        if isinstance(file, str) and file.endswith(".pkl"):
+            self._restore_graphs(os.path.splitext(file)[0] + ".graphs.npz")
         if "Neighbours" not in self.graph:
             self.graph["Neighbours"] = self.build_graph(eps=1, _keep="Neighbours")
 
@@ -503,6 +506,24 @@ class Prograph:
             weights.append([x.cpu().numpy() for x in s[0][:, 1:k + 1]])
             edges.append([x.cpu().numpy() for x in s[1][:, 1:k + 1]])
         return list(zip(flatten(edges), flatten(weights)))
+
+    def _restore_graphs(self, sidecar):
+        """Graphs saved as flat arrays by `utils.save(..., graphs="csr")`: back onto the device, and their
+        columns (the reference's tuple format, views into two host arrays per graph) into the frame."""
+        if not os.path.exists(sidecar):
+            return
+        from .graph import load_graphs
+        for name, g in load_graphs(sidecar).items():
+            if name in self.graph or g.nrows != len(self.graph):
+                continue
+            tuples = g.to_tuples()
+            self.graph[name] = tuples
+            self.csr_graphs[name] = g
+            self._csr_rows[name] = (tuples[0], tuples[len(tuples) // 2], tuples[-1]) if tuples else ()
+
+    def _device_graph_any(self, graph):
+        """The device-resident form (CSRGraph or KNNGraph as built) of a column that still matches it."""
+        return self.csr_graphs.get(graph) if self._device_graph(graph) is not None else None
 
     # ------------------------------------------------------------------ consumers of the graph column
     def _device_graph(self, graph):

@@ -159,6 +159,37 @@ def test_networkx_and_save_roundtrip(pgraph, tmp_path, capsys):
     assert again[0]["Fitness"] == 0.660972597708149               # tests/tests.py:108
 
 
+def test_csr_persistence_without_tuples(pgraph, tmp_path, capsys):
+    """`save(graphs="csr")` writes the graphs as flat arrays (no N tuples in the pickle),
+    the constructor restores them from the side-car and - like the reference with a pickled `Neighbours`
+    column (prograph/prograph.py:140-141) - does not run the N^2 build again."""
+    from prograph_amd import Prograph
+    from prograph_amd.utils import save
+    pgraph.build_graph(k=5, store="K5")
+    pgraph.build_graph(eps=2, similarity=True, store="E2s")
+    assert save(pgraph, name="flat", directory=str(tmp_path) + "/", graphs="csr")
+    frame = pd.read_pickle(tmp_path / "flat.pkl")
+    assert "Neighbours" not in frame and "K5" not in frame and "E2s" not in frame and "Sequence" in frame
+    z = np.load(tmp_path / "flat.graphs.npz", allow_pickle=False)        # plain arrays only
+    assert {"Neighbours/indptr", "Neighbours/indices", "Neighbours/weights", "K5/idx", "K5/dist", "E2s/weights"} <= set(z.files)
+    assert z["Neighbours/indptr"][-1] == 27000 and z["K5/idx"].shape == (1000, 5)
+
+    def no_build(self, *a, **k):
+        raise AssertionError("the constructor rebuilt a graph that was saved")
+    real_build = Prograph.build_graph
+    Prograph.build_graph = no_build
+    try:
+        again = Prograph(file=str(tmp_path / "flat.pkl"))
+    finally:
+        Prograph.build_graph = real_build
+    for name in ("Neighbours", "K5", "E2s"):
+        a, b = list(again.graph[name]), list(pgraph.graph[name])
+        assert all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[1].dtype == y[1].dtype for x, y in zip(a, b))
+        assert again._device_graph(name) is not None
+        assert np.array_equal(again.degree(name), pgraph.degree(name))
+    assert np.allclose(again.dirichlet("K5"), pgraph.dirichlet("K5"), rtol=1e-12)
+
+
 # ---------------------------------------------------------------- tests/tests.py:124-133
 def test_tokenization(pgraph):
     assert np.all(pgraph.tokenize("ACA") == np.array([1, 2, 1]))

@@ -1,37 +1,57 @@
-"""End-to-end wall clock of the user-facing calls at scale (ingest -> graph -> host tuples), by stage.
-usage: tools/e2e_bench.py [N] [L]"""
-import os, sys, time, tempfile, cProfile, pstats
+"""End-to-end wall clock of the user-facing calls at scale, by stage:
+ingest (read_csv, tokenize, reverse map), plane packing, the eps=1 graph of the constructor (device
+CSR), materialisation of the reference's N tuples, kNN, and saving / reloading the graphs as flat arrays.
+usage: tools/e2e_bench.py [N] [L]       (run on the GPU box; prints a table, one line per stage)"""
+import os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pandas as pd, torch
-from prograph_amd import synth
+from prograph_amd import synth, _native
 from prograph_amd.prograph import Prograph
+from prograph_amd.utils import save
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+rows = []
+
+
+def timed(label, f):
+    torch.cuda.synchronize(); t = time.perf_counter(); r = f(); torch.cuda.synchronize()
+    rows.append((label, time.perf_counter() - t)); print(f"{label:62s} {rows[-1][1]:9.3f} s", flush=True)
+    return r
+
+
+print(f"N={N} L={L}  (clustered synthetic sequences, 256 per cluster)")
 tok = synth.clustered_tokens(N, L)
-t0 = time.time(); seqs = synth.tokens_to_strings(tok); print(f"strings {time.time()-t0:.2f}s", flush=True)
+seqs = synth.tokens_to_strings(tok)
 df = pd.DataFrame({"Sequence": seqs, "Fitness": np.random.RandomState(0).rand(N)})
 tmp = tempfile.mkdtemp(); path = os.path.join(tmp, "synthetic.csv"); df.to_csv(path)
 torch.zeros(1, device="cuda"); torch.cuda.synchronize()
 
-def timed(label, f):
-    torch.cuda.synchronize(); t = time.time(); r = f(); torch.cuda.synchronize(); print(f"{label:46s} {time.time()-t:8.3f} s", flush=True); return r
+# the constructor's stages one by one (what Prograph.__init__ does, prograph/prograph.py:96-144 of the reference)
+frame = timed("pd.read_csv", lambda: pd.read_csv(path, index_col=0))
+probe = Prograph.__new__(Prograph)
+probe.amino_acids = "ACDEFGHIKLMNPQRSTVWY"
+probe.tokens = {aa.encode("utf-8"): i for i, aa in enumerate(probe.amino_acids, start=1)}
+tokens = timed("tokenize (one table lookup over the byte view)", lambda: probe.tokenize(frame["Sequence"]))
+timed("seq_idxs reverse map (dict of N strings)", lambda: dict(zip(frame["Sequence"], range(len(frame)))))
+planes = timed("H2D + pg_pack_planes (uint8 tokens -> planes + signatures)", lambda: _native.pack(torch.from_numpy(tokens.astype(np.uint8)), bits=5))
+csr = timed("eps<=1 graph: slots + scan + compact (device CSR)", lambda: _native.eps_graph(planes, planes, _native.CMP_LE, 1))
+print(f"    nnz = {csr[1].numel()}")
+from prograph_amd.graph import CSRGraph
+g = CSRGraph(*csr, planes.n)
+tup = timed("CSRGraph.to_tuples (the reference's N (idx, w) tuples)", g.to_tuples)
+timed("DataFrame column assignment of the N tuples", lambda: frame.__setitem__("Neighbours", tup))
+del frame, tup, g, csr, planes
 
-pr = cProfile.Profile(); pr.enable()
-pg = timed("Prograph(csv)  [ingest + eps=1 graph + print]", lambda: Prograph(path))
-pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
-timed("build_graph(k=16) -> tuples", lambda: pg.build_graph(k=16))
+pg = timed("Prograph(csv)  [all of the above + summary print]", lambda: Prograph(path))
 timed("build_graph(k=16, output='csr')", lambda: pg.build_graph(k=16, output="csr"))
-timed("build_graph(eps=2) -> tuples", lambda: pg.build_graph(eps=2))
+timed("build_graph(k=16) -> tuples", lambda: pg.build_graph(k=16))
 timed("build_graph(eps=2, output='csr')", lambda: pg.build_graph(eps=2, output="csr"))
-for _ in range(2):
-    timed("build_graph(k=16, output='csr') again", lambda: pg.build_graph(k=16, output="csr"))
-pr = cProfile.Profile(); pr.enable()
-timed("build_graph(k=16, output='csr') profiled", lambda: pg.build_graph(k=16, output="csr"))
-pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
-pr = cProfile.Profile(); pr.enable()
-timed("build_graph(eps=2) -> tuples profiled", lambda: pg.build_graph(eps=2))
-pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+timed("degree() from the device CSR", lambda: pg.degree())
 timed("indexing(positions=[3, 7])", lambda: pg.indexing(positions=[3, 7]))
-timed("degree()", lambda: pg.degree())
+timed("save(graphs='csr')  [frame pickle + flat .npz side-car]", lambda: save(pg, name="flat", directory=tmp + "/", graphs="csr"))
+timed("save()  [reference format: pickle with N tuples]", lambda: save(pg, name="tuples", directory=tmp + "/"))
+timed("Prograph('flat.pkl')  [graphs restored, no N^2 build]", lambda: Prograph(os.path.join(tmp, "flat.pkl")))
+timed("Prograph('tuples.pkl')  [reference format]", lambda: Prograph(os.path.join(tmp, "tuples.pkl")))
+for f in ("flat.pkl", "flat.graphs.npz", "tuples.pkl"):
+    print(f"    {f}: {os.path.getsize(os.path.join(tmp, f)) / 1e6:.1f} MB")
