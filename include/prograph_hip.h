@@ -280,6 +280,33 @@ int pg_compact_flags(const uint8_t *flags, int64_t n, int64_t *out_idx, int64_t 
                      void *scratch, void *stream);
 
 /*
+ * Minkowski (p = 2) graphs of fp16 embeddings: `build_graph(representation="Embedded",
+ * distance=minkowski)`, prograph/distance/minkowski.py:8-41 through prograph/prograph.py:726-764.  Every
+ * elementwise step rounds to fp16 exactly as the reference's fp16 tensor expression does (difference,
+ * square, sum, root, and 1/(1+d) for similarities); see prograph_amd/csrc/pg_mink.hip for the tolerance.
+ *   pg_pack_f16          (n, d) fp16 row-major (leading dimension ld elements, optional row gather list)
+ *                        -> chunk-major: chunk q (8 halfs) of vector n at byte (q*npad + n)*16;
+ *                        buffer pg_f16_nchunks(d) * npad * 16 bytes
+ *   pg_minkowski_dense   out[m*ldo + n] = fp16 distance (similarity != 0: 1/(1+d)) of Y[m] and X[n]
+ *   pg_f16_knn           ranks first..first+k-1 of every row of such a block in (value, column) order
+ *                        (descending != 0: largest first, the similarity sort of :758); first + k <= 64
+ *   pg_f16_eps_count/_fill  comp(d, eps) & (d > 0)  [similarities: comp(eps, s) & (s < 1)], eps_f16 = the
+ *                        threshold rounded to fp16 as torch does when it compares an fp16 tensor with a
+ *                        Python number; count -> pg_exclusive_scan -> fill (columns ascending, fp16 weights)
+ */
+int pg_f16_nchunks(int d);
+int pg_pack_f16(const void *src_f16, int64_t n, int d, int64_t ld, const int64_t *rows, void *packed, int64_t npad,
+                void *stream);
+int pg_minkowski_dense(const void *x_packed, int64_t n, int64_t x_npad, const void *y_packed, int64_t m,
+                       int64_t y_npad, int d, int similarity, void *out_f16, int64_t ldo, void *stream);
+int pg_f16_knn(const void *dist_f16, int64_t m, int64_t n, int64_t ld, int k, int first, int descending,
+               int32_t *idx_out, void *w_out_f16, void *stream);
+int pg_f16_eps_count(const void *dist_f16, int64_t m, int64_t n, int64_t ld, int cmp, float eps_f16, int similarity,
+                     uint32_t *counts, void *stream);
+int pg_f16_eps_fill(const void *dist_f16, int64_t m, int64_t n, int64_t ld, int cmp, float eps_f16, int similarity,
+                    const int64_t *indptr, int32_t *indices, void *weights_f16, void *stream);
+
+/*
  * Multi-GPU: the path's ONE collective (e).  The N^2 pair space shards row-block
  * wise, one process per GPU; every rank needs the whole token matrix, so the ranks all-gather their
  * row shards once (RCCL over xGMI: 64 MB at N = 1M, L = 64) and never talk again.  The reference has

@@ -237,8 +237,69 @@ def gen_hamming_kats():
     print("hamming_kats", len(d))
 
 
+KNNTEST_EMBEDDING = np.array([[0, 0], [0.5, 0], [3.75, 0], [2.75, 0], [4.0, 1.4], [4.75, 1.15]], dtype=np.float64)
+
+
+def gen_minkowski():
+    """`build_graph(representation="Embedded", distance=minkowski)` of the real reference
+    (prograph/distance/minkowski.py:8-41 through prograph/prograph.py:726-764: fp16 staging, fp16
+    elementwise arithmetic).  data/knntest_pgraph.pkl is a pickle and is not loaded; the 2-D embedding
+    below was constructed to satisfy every known answer tests/tests.py:139-167 pins on that file
+    (asserted here against the reference itself), the sequences / fitness come from data/knntest.csv."""
+    from prograph.distance import minkowski as ref_mink
+    d = {}
+    os.chdir(REF)
+    pg = quiet(Prograph, file="data/knntest.csv")
+    pg.graph["Embedded"] = list(KNNTEST_EMBEDDING)
+    proxy.stable = True
+    L1 = quiet(pg.build_graph, representation="Embedded", k=1, distance=ref_mink)
+    L2 = quiet(pg.build_graph, representation="Embedded", k=2, distance=ref_mink)
+    assert np.all(np.array([x[0] for x in L1]).reshape(-1) == np.array([1, 0, 3, 2, 5, 4]))               # tests.py:141-144
+    assert np.all(np.array([x[0] for x in L2]) == np.array([[1, 3], [0, 3], [3, 4], [2, 4], [5, 2], [4, 2]]))   # :145-148
+    pg.graph["Weighted"] = quiet(pg.build_graph, eps=2, representation="Embedded", distance=ref_mink)
+    assert np.allclose(pg.degree(graph="Weighted", boolean_weights=True), [1, 1, 3, 2, 3, 2])            # :159-162
+    pg.graph["W1"] = L1
+    assert np.allclose(pg.degree(graph="W1"), [0.5, 0.5, 1., 1., 0.79052734, 0.79052734], atol=1e-7)       # :164-167
+    d["knntest_emb"] = KNNTEST_EMBEDDING
+    d["knntest_fitness"] = pg("Fitness").to_numpy()
+    for k in (1, 2, 5):
+        L = quiet(pg.build_graph, representation="Embedded", k=k, distance=ref_mink)
+        d[f"knntest_knn{k}_idx"] = np.stack([x[0] for x in L]).astype(np.int32)
+        d[f"knntest_knn{k}_w"] = np.stack([x[1] for x in L])
+    store_eps(d, "knntest_eps2", list(pg.graph["Weighted"]))
+    d["knntest_deg_w1"] = pg.degree(graph="W1")
+    # seeded fp16 sets through the same reference path (D = 2, 64, 1280)
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, n, dim, seed in (("d2", 300, 2, 1), ("d64", 1000, 64, 2), ("d1280", 512, 1280, 3)):
+            rng = np.random.RandomState(seed)
+            centres = rng.randn(max(1, n // 20), dim)
+            emb = (centres[rng.randint(0, len(centres), size=n)] + 0.35 * rng.randn(n, dim)).astype(np.float16)
+            emb[n // 2] = emb[3]                                   # an exact duplicate (d == 0 is excluded, rank 0 rule)
+            tok = synth.clustered_tokens(n, 8, seed=synth.DEFAULT_SEED + 40 + seed)
+            pgs = quiet(Prograph, file=make_csv(tmp, "mink_" + name, tok, 20 + seed))
+            pgs.graph["Embedded"] = list(emb)
+            d[f"{name}_emb"] = emb
+            dist = ref_mink(torch.as_tensor(emb, dtype=torch.float16), torch.as_tensor(emb[:64], dtype=torch.float16))
+            d[f"{name}_dist64"] = dist.numpy()                     # (64, n) fp16 block of the operator itself
+            eps = float(np.float16(np.quantile(dist.numpy().astype(np.float64), 0.03)))
+            d[f"{name}_eps"] = np.float64(eps)
+            store_eps(d, f"{name}_eps", quiet(pgs.build_graph, eps=eps, representation="Embedded", distance=ref_mink))
+            store_eps(d, f"{name}_eps_sim", quiet(pgs.build_graph, eps=eps, similarity=True, representation="Embedded", distance=ref_mink))
+            for k in (1, 5, 16):
+                L = quiet(pgs.build_graph, representation="Embedded", k=k, distance=ref_mink)
+                d[f"{name}_knn{k}_idx"] = np.stack([x[0] for x in L]).astype(np.int32)
+                d[f"{name}_knn{k}_w"] = np.stack([x[1] for x in L])
+            L = quiet(pgs.build_graph, representation="Embedded", k=4, similarity=True, distance=ref_mink)
+            d[f"{name}_knn4_sim_idx"] = np.stack([x[0] for x in L]).astype(np.int32)
+            d[f"{name}_knn4_sim_w"] = np.stack([x[1] for x in L])
+    proxy.stable = False
+    np.savez_compressed(os.path.join(OUT, "minkowski_f16.npz"), **d)
+    print("minkowski_f16", {k: (v.shape, str(v.dtype)) for k, v in d.items() if "knn5" in k or "eps_w" in k})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    gen_minkowski()
     gen_reference_csv()
     gen_hamming_kats()
     with tempfile.TemporaryDirectory() as tmp:

@@ -71,6 +71,19 @@ def hamming(X, Y, similarity=False):
 # --------------------------------------------------------------------------------------
 # a4  get_every_n                                        prograph/prograph.py:617-624
 # --------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------
+# f2  minkowski                                          prograph/distance/minkowski.py:8-41
+# --------------------------------------------------------------------------------------
+def minkowski(X, Y, p=2, similarity=False):
+    """The reference's tensor expression verbatim in meaning: with fp16 operands (build_graph stages the
+    embedding as fp16, prograph/prograph.py:726) every elementwise step rounds to fp16."""
+    X, Y = clean_input(X, Y)
+    distances = torch.pow(torch.sum(torch.pow(X - Y[:, None, :], exponent=p), axis=2), exponent=1 / p)   # :36
+    if similarity:
+        distances = 1 / (1 + distances)                                                             # :40
+    return distances
+
+
 def get_every_n(a, n=2):
     for i in range((a.shape[0] // n) + (a.shape[0] % n > 0)):
         yield a[n * i:n * (i + 1)]

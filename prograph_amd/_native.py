@@ -31,6 +31,7 @@ SYMBOLS = [
     "pg_eps_compact", "pg_eps_fill_rows", "pg_eps_slots_sym", "pg_eps_compact_sym", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
     "pg_lev_profile", "pg_lev_candidates", "pg_lev_candidates_sym", "pg_lev_knn", "pg_csr_row_stats",
     "pg_comm_unique_id", "pg_comm_init", "pg_comm_destroy", "pg_allgather_tokens",
+    "pg_f16_nchunks", "pg_pack_f16", "pg_minkowski_dense", "pg_f16_knn", "pg_f16_eps_count", "pg_f16_eps_fill",
 ]
 
 
@@ -102,6 +103,12 @@ def _load():
         lib.pg_lev_candidates_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_lev_knn.argtypes = [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp]
+        lib.pg_f16_nchunks.argtypes = [_i32]
+        lib.pg_pack_f16.argtypes = [_vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp]
+        lib.pg_minkowski_dense.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]
+        lib.pg_f16_knn.argtypes = [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
+        lib.pg_f16_eps_count.argtypes = [_vp, _i64, _i64, _i64, _i32, ctypes.c_float, _i32, _vp, _vp]
+        lib.pg_f16_eps_fill.argtypes = [_vp, _i64, _i64, _i64, _i32, ctypes.c_float, _i32, _vp, _vp, _vp, _vp]
         lib.pg_comm_unique_id.argtypes = [_vp]
         lib.pg_comm_init.argtypes = [ctypes.POINTER(_vp), _i32, _i32, _vp]
         lib.pg_comm_destroy.argtypes = [_vp]
@@ -486,6 +493,69 @@ def csr_row_stats(indptr, indices, weights, f=None, want=("deg",), row0=0, ncols
                                   _ptr(out.get("deg")), _ptr(out.get("sum_f")), _ptr(out.get("sum_wf")),
                                   _ptr(out.get("self_w")), _ptr(out.get("col_sum")), _stream()), "pg_csr_row_stats")
     return out
+
+
+class PackedF16:
+    """Device-resident fp16 vectors in chunk-major order (pg_pack_f16)."""
+    __slots__ = ("buf", "n", "d", "npad")
+
+    def __init__(self, buf, n, d):
+        self.buf, self.n, self.d, self.npad = buf, int(n), int(d), npad(n)
+
+
+def pack_f16(x):
+    """(N, D) fp16 device tensor -> PackedF16."""
+    if x.dtype != torch.float16 or x.dim() != 2 or not x.is_cuda or x.shape[0] == 0 or x.shape[1] == 0:
+        raise TypeError("pack_f16 expects a non-empty 2-D fp16 device tensor")
+    x = x.contiguous()
+    n, d = x.shape
+    np_ = npad(n)
+    buf = torch.empty(((d + 7) // 8) * np_ * 16, dtype=torch.uint8, device=x.device)
+    _check(lib().pg_pack_f16(_ptr(x), n, d, x.stride(0), None, _ptr(buf), np_, _stream()), "pg_pack_f16")
+    return PackedF16(buf, n, d)
+
+
+def minkowski_dense(xp, yp, similarity=False):
+    """(M, N) fp16 block: Minkowski p=2 distance (or 1/(1+d)) of every Y vector against every X vector,
+    rounded step by step like the reference's fp16 tensor expression (minkowski.py:36-40)."""
+    if xp.d != yp.d:
+        raise ValueError("operands must have the same dimension")
+    out = torch.empty((yp.n, xp.n), dtype=torch.float16, device=xp.buf.device)
+    _check(lib().pg_minkowski_dense(_ptr(xp.buf), xp.n, xp.npad, _ptr(yp.buf), yp.n, yp.npad, xp.d, 1 if similarity else 0,
+                                    _ptr(out), out.stride(0), _stream()), "pg_minkowski_dense")
+    return out
+
+
+def f16_knn(block, k, first=1, descending=False):
+    """Ranks first..first+k-1 of every row of an fp16 block in (value, column) order -> (idx int32, w fp16)."""
+    m, n = block.shape
+    idx = torch.empty((m, k), dtype=torch.int32, device=block.device)
+    w = torch.empty((m, k), dtype=torch.float16, device=block.device)
+    _check(lib().pg_f16_knn(_ptr(block), m, n, block.stride(0), int(k), int(first), 1 if descending else 0, _ptr(idx), _ptr(w),
+                            _stream()), "pg_f16_knn")
+    return idx, w
+
+
+def f16_eps(block, cmp, eps, similarity=False):
+    """CSR of the entries of an fp16 block that satisfy comp(d, eps) & (d > 0)  [comp(eps, s) & (s < 1)].
+    `eps` is rounded to fp16 first, as torch does when an fp16 tensor meets a Python number."""
+    L = lib()
+    m, n = block.shape
+    dev = block.device
+    e16 = float(np.float16(eps))
+    counts = torch.empty(m, dtype=torch.int32, device=dev)
+    _check(L.pg_f16_eps_count(_ptr(block), m, n, block.stride(0), int(cmp), e16, 1 if similarity else 0, _ptr(counts), _stream()),
+           "pg_f16_eps_count")
+    indptr = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    scratch = torch.empty(int(L.pg_scan_scratch_bytes(m)), dtype=torch.uint8, device=dev)
+    _check(L.pg_exclusive_scan(_ptr(counts), m, _ptr(indptr), _ptr(scratch), _stream()), "pg_exclusive_scan")
+    nnz = int(indptr[-1].item())
+    indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+    weights = torch.empty(max(nnz, 1), dtype=torch.float16, device=dev)[:nnz]
+    if nnz:
+        _check(L.pg_f16_eps_fill(_ptr(block), m, n, block.stride(0), int(cmp), e16, 1 if similarity else 0, _ptr(indptr),
+                                 _ptr(indices), _ptr(weights), _stream()), "pg_f16_eps_fill")
+    return indptr, indices, weights
 
 
 COMM_ID_BYTES = 128

@@ -13,6 +13,7 @@
 
 static thread_local char g_err[256] = "";
 
+void pg_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 static int fail(int code, const char *msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
   return code;

@@ -261,6 +261,8 @@ struct CompactParams {
   unsigned char *weights;
 };
 
+void pg_set_error(const char *msg);   // thread-local message behind pg_last_error() (pg_api.hip)
+
 // per-(G,B) launchers (pg_nsq_inst.hip is compiled once per group count G = 1..4)
 #define PG_DECL_G(G)                                                                          \
   int pg_launch_nsq_g##G(int mode, int bits, const NsqParams &p, int grid, hipStream_t s);   \

@@ -33,7 +33,7 @@ import pandas as pd
 import torch
 
 from . import _native
-from .distance import hamming
+from .distance import hamming, minkowski
 from .graph import CSRGraph, KNNGraph
 from .protein import Protein
 from .utils import Dataset, flatten
@@ -437,6 +437,10 @@ class Prograph:
                 idxs = np.asarray(idxs)
                 if idxs.dtype == bool:
                     idxs = np.nonzero(idxs)[0]
+        if distance is minkowski and comp in _CMP_CODE and (k is None or k <= _native.MAX_K):
+            out = self._build_graph_minkowski(idxs, eps, k, similarity, representation, comp)
+            if out is not None:
+                return out
         native = distance is hamming and (comp in _CMP_CODE) and (k is None or k <= _native.MAX_K_ROUNDS)
         planes = None
         if native:
@@ -471,6 +475,48 @@ class Prograph:
         if output == "csr":
             return g
         return tuples if tuples is not None else g.to_tuples()
+
+    def _build_graph_minkowski(self, idxs, eps, k, similarity, representation, comp):
+        """
+        `build_graph(representation=<embedding>, distance=minkowski)` on the HIP kernels:
+        the fp16 staging of the reference (:726), then per block of rows the fp16 distance matrix
+        (`pg_minkowski_dense`, rounding like the reference's fp16 tensor ops) and the selection on the
+        device - the canonical (value, column) ranks 1..k (`pg_f16_knn`; the reference drops sorted rank
+        0, :761-763) or the thresholded CSR (`pg_f16_eps_*`; :734-739).  Returns None when the
+        representation is not a numeric matrix (the generic path then reports as the reference would).
+        """
+        try:
+            mat = np.vstack(self(representation))
+            X = torch.as_tensor(mat, dtype=torch.float16, device=_native.device())
+        except (ValueError, TypeError):
+            return None
+        if X.dim() != 2 or X.shape[0] == 0 or X.shape[1] == 0 or not X.is_cuda:
+            return None
+        if idxs is not None:
+            X = X[torch.as_tensor(np.asarray(idxs), device=X.device)]
+        n = X.shape[0]
+        if similarity and eps:
+            eps = 1 / (1 + eps)                                          # :720-721
+        xp = _native.pack_f16(X)
+        rows_per_block = max(64, min(n, (1 << 27) // max(n, 1)))          # <= 256 MB of fp16 distances at a time
+        out = []
+        empty = (np.array([], dtype=int), np.array([], dtype=int))
+        for r0 in range(0, n, rows_per_block):
+            yp = _native.pack_f16(X[r0:r0 + rows_per_block])
+            block = _native.minkowski_dense(xp, yp, similarity=similarity)
+            if k:
+                kk = min(k, n - 1)
+                idx, w = _native.f16_knn(block, kk, first=1, descending=similarity) if kk else (None, None)
+                if kk:
+                    idx, w = idx.to(torch.int64).cpu().numpy(), w.cpu().numpy()
+                    out.extend(zip(list(idx), list(w)))
+                else:
+                    out.extend((np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.float16)) for _ in range(block.shape[0]))
+            else:
+                indptr, indices, wts = _native.f16_eps(block, _CMP_CODE[comp], eps, similarity=similarity)
+                ip, ix, ww = indptr.cpu().numpy(), indices.to(torch.int64).cpu().numpy(), wts.cpu().numpy()
+                out.extend((ix[a:b], ww[a:b]) if b > a else empty for a, b in zip(ip[:-1].tolist(), ip[1:].tolist()))
+        return out
 
     def _build_graph_generic(self, idxs, batch_size, eps, k, similarity, representation, distance, comp):
         """

@@ -719,3 +719,51 @@ def test_allgather_tokens_through_the_c_abi(nat):
         assert full.shape == tok.shape and torch.equal(full, tok)
     finally:
         nat.comm_destroy(comm)
+
+
+def test_minkowski_f16_against_the_reference(nat):
+    """
+    SURVEY.md §8 f2 through the C ABI: pg_pack_f16 + pg_minkowski_dense + pg_f16_knn / pg_f16_eps_* against
+    outputs of the REAL reference (tests/golden/minkowski_f16.npz, oracle/gen_golden.py::gen_minkowski).
+    Float tolerance: the kernel rounds every elementwise step to fp16 like the reference's fp16 tensor
+    expression; only the float accumulation order of the sum differs, which can move a result by ONE fp16
+    ulp when the sum sits on a rounding boundary: none at D <= 64 (bit-exact), < 0.1 % of the pairs at
+    D = 1280.  Graph indices are compared exactly wherever the golden weights are not 1-ulp ties.
+    """
+    g = load_golden("minkowski_f16")
+    dev = nat.device()
+    for name in ("d2", "d64", "d1280"):
+        e = torch.from_numpy(g[f"{name}_emb"]).to(dev)
+        n = e.shape[0]
+        xp = nat.pack_f16(e)
+        blk = nat.minkowski_dense(xp, nat.pack_f16(e[:64]))
+        got, want = blk.cpu().numpy(), g[f"{name}_dist64"]
+        ulp = np.abs(got.view(np.int16).astype(np.int64) - want.view(np.int16).astype(np.int64))
+        if name == "d1280":
+            assert ulp.max() <= 1 and (ulp != 0).mean() < 1e-3, (name, int(ulp.max()), float((ulp != 0).mean()))
+        else:
+            assert ulp.max() == 0, (name, int(ulp.max()))
+        full = nat.minkowski_dense(xp, xp)
+        for k in (1, 5, 16):
+            idx, w = nat.f16_knn(full, k, first=1)
+            idx, w = idx.cpu().numpy(), w.cpu().numpy()
+            wi, ww = g[f"{name}_knn{k}_idx"], g[f"{name}_knn{k}_w"]
+            wulp = np.abs(w.view(np.int16).astype(np.int64) - ww.view(np.int16).astype(np.int64))
+            assert wulp.max() <= (1 if name == "d1280" else 0)
+            same = (idx == wi).all(1)
+            assert same.mean() >= (0.995 if name == "d1280" else 1.0), (name, k, float(same.mean()))
+        sidx, sw = nat.f16_knn(nat.minkowski_dense(xp, xp, similarity=True), 4, first=1, descending=True)
+        same = (sidx.cpu().numpy() == g[f"{name}_knn4_sim_idx"]).all(1)
+        assert same.mean() >= (0.995 if name == "d1280" else 1.0)
+        if name != "d1280":
+            assert np.array_equal(sw.cpu().numpy(), g[f"{name}_knn4_sim_w"])
+        eps = float(g[f"{name}_eps"])
+        for sim, key in ((False, "eps"), (True, "eps_sim")):
+            blk = nat.minkowski_dense(xp, xp, similarity=sim)
+            ip, ix, w = nat.f16_eps(blk, nat.CMP_LE, 1 / (1 + eps) if sim else eps, similarity=sim)
+            ip, ix, w = ip.cpu().numpy(), ix.cpu().numpy(), w.cpu().numpy()
+            if name == "d1280":          # an entry whose distance sits one ulp across the threshold may differ
+                assert abs(int(ip[-1]) - int(g[f"{name}_{key}_indptr"][-1])) <= 0.002 * int(ip[-1]) + 2
+            else:
+                assert np.array_equal(ip, g[f"{name}_{key}_indptr"]) and np.array_equal(ix, g[f"{name}_{key}_indices"])
+                assert np.array_equal(w.astype(np.float64), g[f"{name}_{key}_weights"].astype(np.float64))

@@ -193,3 +193,27 @@ def test_c_oracle_matches_python_oracle():
         assert np.array_equal(C.synth(n, l, seed, mem), synth.clustered_tokens(n, l, seed=seed, members=mem))
     ip, ix, w = C.eps_csr(g["tokens"], 0, 1, row0=100, nrows=50)
     assert np.array_equal(ip, g["eps1_indptr"][100:151] - g["eps1_indptr"][100])
+
+
+def test_minkowski_oracle_is_pinned_to_the_reference():
+    """the fp16 Minkowski restatement against outputs of the real reference
+    (oracle/gen_golden.py::gen_minkowski), including the known answers of tests/tests.py:139-167."""
+    g = load_golden("minkowski_f16")
+    emb = g["knntest_emb"]
+    L1 = O.build_graph(emb, k=1, distance=O.minkowski)
+    assert np.array_equal(np.array([x[0] for x in L1]).reshape(-1), [1, 0, 3, 2, 5, 4])                       # tests.py:141-144
+    L2 = O.build_graph(emb, k=2, distance=O.minkowski)
+    assert np.array_equal(np.array([x[0] for x in L2]), [[1, 3], [0, 3], [3, 4], [2, 4], [5, 2], [4, 2]])     # :145-148
+    assert np.allclose(O.degree(L1), [0.5, 0.5, 1., 1., 0.79052734, 0.79052734], atol=1e-7)                   # :164-167
+    E2 = O.build_graph(emb, eps=2, distance=O.minkowski)
+    assert np.array_equal(O.degree(E2, boolean_weights=True), [1, 1, 3, 2, 3, 2])                             # :159-162
+    for name in ("d2", "d64", "d1280"):
+        e = g[f"{name}_emb"]
+        d = O.minkowski(torch.as_tensor(e), torch.as_tensor(e[:64]))
+        assert d.dtype == torch.float16 and np.array_equal(d.numpy(), g[f"{name}_dist64"])
+        for k in (1, 5, 16):
+            idx, w = O.neighbours_to_knn(O.build_graph(e, k=k, distance=O.minkowski))
+            assert np.array_equal(idx, g[f"{name}_knn{k}_idx"]) and np.array_equal(w, g[f"{name}_knn{k}_w"])
+        ip, ix, w = O.neighbours_to_csr(O.build_graph(e, eps=float(g[f"{name}_eps"]), distance=O.minkowski))
+        assert np.array_equal(ip, g[f"{name}_eps_indptr"]) and np.array_equal(ix, g[f"{name}_eps_indices"])
+        assert np.array_equal(np.asarray(w, dtype=np.float64), g[f"{name}_eps_weights"].astype(np.float64))

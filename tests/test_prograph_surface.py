@@ -520,7 +520,47 @@ def test_knn_graph_generation_minkowski(knn_test):
     np.testing.assert_almost_equal(knn_test.degree(graph="Weighted", boolean_weights=True), np.array([1, 1, 3, 2, 3, 2]))
     knn_test.graph["Weighted"] = knn_test.build_graph(k=1, representation="Embedded", distance=minkowski)
     # fp16 staging like the reference (prograph.py:726): sqrt(0.625) rounds to 0.79052734
-    np.testing.assert_almost_equal(knn_test.degree(graph="Weighted"), np.array([0.5, 0.5, 1., 1., 0.79052734, 0.79052734]), decimal=3)
+    np.testing.assert_almost_equal(knn_test.degree(graph="Weighted"), np.array([0.5, 0.5, 1., 1., 0.79052734, 0.79052734]), decimal=7)
+
+
+def test_minkowski_graphs_match_the_reference(backend, tmp_path, capsys):
+    """`build_graph(representation="Embedded", distance=minkowski)` against outputs of the real reference
+    (tests/golden/minkowski_f16.npz): the knntest embedding of the golden generator and a seeded
+    (1000, 64) fp16 set - bit-exact at these dimensions, tuple formats and dtypes as the reference's."""
+    from prograph_amd import Prograph
+    from prograph_amd.distance import minkowski
+    g = load_golden("minkowski_f16")
+    f = tmp_path / "knntest.csv"
+    pd.DataFrame({"Sequence": list("ACDEFG"), "Fitness": g["knntest_fitness"]}).to_csv(f)
+    pg = Prograph(file=str(f))
+    pg.graph["Embedded"] = list(g["knntest_emb"])
+    for k in (1, 2, 5):
+        L = pg.build_graph(representation="Embedded", k=k, distance=minkowski)
+        assert np.array_equal(np.stack([x[0] for x in L]), g[f"knntest_knn{k}_idx"]) and L[0][0].dtype == np.int64
+        assert np.array_equal(np.stack([x[1] for x in L]), g[f"knntest_knn{k}_w"]) and L[0][1].dtype == np.float16
+    pg.graph["W1"] = pg.build_graph(representation="Embedded", k=1, distance=minkowski)
+    assert np.array_equal(pg.degree("W1"), g["knntest_deg_w1"])               # 0.79052734 included, bit for bit
+    n = 1000
+    tok = synth.clustered_tokens(n, 8, seed=synth.DEFAULT_SEED + 42)
+    f2 = tmp_path / "d64.csv"
+    pd.DataFrame({"Sequence": synth.tokens_to_strings(tok), "Fitness": np.zeros(n)}).to_csv(f2)
+    pg = Prograph(file=str(f2))
+    capsys.readouterr()
+    pg.graph["Embedded"] = list(g["d64_emb"])
+    for k in (1, 5, 16):
+        L = pg.build_graph(representation="Embedded", k=k, distance=minkowski)
+        assert np.array_equal(np.stack([x[0] for x in L]), g[f"d64_knn{k}_idx"])
+        assert np.array_equal(np.stack([x[1] for x in L]), g[f"d64_knn{k}_w"])
+    L = pg.build_graph(representation="Embedded", k=4, similarity=True, distance=minkowski)
+    assert np.array_equal(np.stack([x[0] for x in L]), g["d64_knn4_sim_idx"]) and np.array_equal(np.stack([x[1] for x in L]), g["d64_knn4_sim_w"])
+    for sim, key in ((False, "d64_eps"), (True, "d64_eps_sim")):
+        E = pg.build_graph(representation="Embedded", eps=float(g["d64_eps"]), similarity=sim, distance=minkowski)
+        ip = np.concatenate([[0], np.cumsum([len(e[0]) for e in E])])
+        assert np.array_equal(ip, g[key + "_indptr"])
+        assert np.array_equal(np.concatenate([e[0] for e in E]), g[key + "_indices"])
+        assert np.array_equal(np.concatenate([np.asarray(e[1], dtype=np.float64) for e in E]), g[key + "_weights"].astype(np.float64))
+        empty = [e for e in E if len(e[0]) == 0]
+        assert all(e[0].dtype == np.int64 or e[0].dtype == int for e in E) and all(e[1].dtype == int for e in empty)
 
 
 def test_minkowski_operator(backend):

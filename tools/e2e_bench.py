@@ -48,7 +48,8 @@ timed("build_graph(k=16, output='csr')", lambda: pg.build_graph(k=16, output="cs
 timed("build_graph(k=16) -> tuples", lambda: pg.build_graph(k=16))
 timed("build_graph(eps=2, output='csr')", lambda: pg.build_graph(eps=2, output="csr"))
 timed("degree() from the device CSR", lambda: pg.degree())
-timed("indexing(positions=[3, 7])", lambda: pg.indexing(positions=[3, 7]))
+timed("neighbourhood(seed, eps=4)  [1xN Hamming + select]", lambda: pg.neighbourhood(pg.seed.Sequence, 4))
+timed("calc_neighbours(seed, eps=2, comp=le)", lambda: pg.calc_neighbours(pg.seed.Sequence, eps=2, comp=__import__("operator").le))
 timed("save(graphs='csr')  [frame pickle + flat .npz side-car]", lambda: save(pg, name="flat", directory=tmp + "/", graphs="csr"))
 timed("save()  [reference format: pickle with N tuples]", lambda: save(pg, name="tuples", directory=tmp + "/"))
 timed("Prograph('flat.pkl')  [graphs restored, no N^2 build]", lambda: Prograph(os.path.join(tmp, "flat.pkl")))
