@@ -9,12 +9,12 @@
 // (tests/tests.py:164-167: sqrt(0.625) -> 0.79052734).  The kernel reproduces the same sequence:
 //     diff = v_pk_add_f16(x, -y)        rounded to fp16, two elements per instruction
 //     sq   = v_pk_mul_f16(diff, diff)   rounded to fp16
-//     acc += sq.lo + sq.hi              v_dot2_f32_f16 against (1, 1): exact products, fp32 sum per chunk,
-//                                       float64 across chunks (the reference's float accumulation is
-//                                       order dependent; a near-exact sum is its most likely value)
+//     acc += sq.lo + sq.hi              v_dot2c_f32_f16 against (1, 1): exact products, fp32 accumulation in
+//                                       element order like the reference's float accumulator (whose own
+//                                       order is implementation defined: torch vectorises it)
 //     d    = fp16(sqrt(float(fp16(acc))))
-// so distances are bit-identical to the reference for D <= 64 and differ by one fp16 ulp on < 0.05 % of
-// the pairs at D = 1280 (measured against reference-generated goldens, tests/golden/minkowski_f16.npz).
+// so distances are bit-identical to the reference on the goldens up to D = 64 and differ by one fp16 ulp
+// on < 0.05 % of the pairs at D = 1280 (measured against reference-generated goldens, tests/golden/minkowski_f16.npz).
 // This is why the ||x||^2 + ||y||^2 - 2 x.y form on the matrix cores is NOT used: it is ~10x cheaper at
 // large D but does not round like the reference.
 //
@@ -61,9 +61,9 @@ __global__ __launch_bounds__(256) void pg_mink_dense_kernel(const uint4 *__restr
   const long long r0 = (long long)blockIdx.y * MK_ROWS;
   const int nr = (int)((m - r0) < MK_ROWS ? (m - r0) : MK_ROWS);
   const long long c = col < xnpad ? col : xnpad - 1;
-  double acc[MK_ROWS];
+  float acc[MK_ROWS];
 #pragma unroll
-  for (int r = 0; r < MK_ROWS; ++r) acc[r] = 0.0;
+  for (int r = 0; r < MK_ROWS; ++r) acc[r] = 0.0f;
   const pg_h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
   for (int q0 = 0; q0 < nq; q0 += MK_SEG) {
     __syncthreads();
@@ -84,11 +84,10 @@ __global__ __launch_bounds__(256) void pg_mink_dense_kernel(const uint4 *__restr
         const uint4 yv = ybuf[r][qq];
         const pg_h2 d0 = x0 - __builtin_bit_cast(pg_h2, yv.x), d1 = x1 - __builtin_bit_cast(pg_h2, yv.y);
         const pg_h2 d2 = x2 - __builtin_bit_cast(pg_h2, yv.z), d3 = x3 - __builtin_bit_cast(pg_h2, yv.w);
-        float p = __builtin_amdgcn_fdot2(d0 * d0, ones, 0.0f, false);
+        float p = __builtin_amdgcn_fdot2(d0 * d0, ones, acc[r], false);
         p = __builtin_amdgcn_fdot2(d1 * d1, ones, p, false);
         p = __builtin_amdgcn_fdot2(d2 * d2, ones, p, false);
-        p = __builtin_amdgcn_fdot2(d3 * d3, ones, p, false);
-        acc[r] += (double)p;
+        acc[r] = __builtin_amdgcn_fdot2(d3 * d3, ones, p, false);
       }
     }
   }
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256) void pg_mink_dense_kernel(const uint4 *__restr
 #pragma unroll
     for (int r = 0; r < MK_ROWS; ++r) {
       if (r < nr) {
-        const _Float16 s16 = (_Float16)acc[r];                          // the sum as fp16 (one rounding)
+        const _Float16 s16 = (_Float16)acc[r];                          // the float sum as fp16
         __half d16 = __float2half_rn(sqrtf((float)s16));                  // pow(., 1/2) on the fp16 value
         if (similarity) {                                               // 1 / (1 + d): two fp16 roundings (minkowski.py:40)
           const __half t = __float2half_rn(1.0f + __half2float(d16));

