@@ -164,26 +164,35 @@ def planes_bytes(n, l, bits):
 
 
 class Planes:
-    """Device-resident token matrix as bit-sliced records (see include/prograph_hip.h)."""
-    __slots__ = ("buf", "n", "l", "npad", "g", "q", "bits")
+    """Device-resident token matrix as bit-sliced records (see include/prograph_hip.h).
+    `flags`: the device word pg_pack_planes sets when a token does not fit the bit planes; `pack(check=False)`
+    leaves reading it (one host sync) to the caller, `ensure_valid()` does it."""
+    __slots__ = ("buf", "n", "l", "npad", "g", "q", "bits", "flags")
 
-    def __init__(self, buf, n, l, bits):
-        self.buf, self.n, self.l, self.bits = buf, int(n), int(l), int(bits)
+    def __init__(self, buf, n, l, bits, flags=None):
+        self.buf, self.n, self.l, self.bits, self.flags = buf, int(n), int(l), int(bits), flags
         self.npad, self.g, self.q = npad(n), ngroups(l), nchunks(l, bits)
+
+    def ensure_valid(self):
+        if self.flags is not None and int(self.flags.item()):
+            raise ValueError(f"tokens outside 0..{(1 << self.bits) - 1} cannot be packed with {self.bits} bit planes")
+        self.flags = None
 
     @property
     def nbytes(self):
         return self.buf.numel()
 
 
-def pack(tokens, rows=None, bits=None, width=None):
+def pack(tokens, rows=None, bits=None, width=None, check=True):
     """
     (N, L) integer tokens (torch tensor on the GPU, or anything np.asarray takes) -> Planes.
     `rows`: optional index list (the reference's `idxs`, prograph/prograph.py:726).
     `bits`: 5 or 8 bit planes per token; None picks 5 when every token is <= 31, else 8.
     `width`: pack as if the rows were zero right-padded to this length (clean_input's padding).
     Raises ValueError when a token does not fit a byte: such data is not "tokenized" and the
-    caller must take the generic torch path.
+    caller must take the generic torch path.  `check=False` skips the host sync that reads the
+    device-side validity word (callers in a pipeline read `Planes.flags` together with something
+    else they wait for anyway, or call `ensure_valid()` later).
     """
     L = lib()
     dev = device()
@@ -228,9 +237,10 @@ def pack(tokens, rows=None, bits=None, width=None):
     flags = torch.zeros(1, dtype=torch.int32, device=dev)
     _check(L.pg_pack_planes(_ptr(tokens), tokens.element_size(), n, lw, tokens.stride(0), _ptr(ridx), int(bits),
                             _ptr(buf), np_, _ptr(flags), _stream()), "pg_pack_planes")
-    if int(flags.item()):
-        raise ValueError(f"tokens outside 0..{(1 << bits) - 1} cannot be packed with {bits} bit planes")
-    return Planes(buf, n, lw, bits)
+    planes = Planes(buf, n, lw, bits, flags)
+    if check:
+        planes.ensure_valid()
+    return planes
 
 
 _TORCH_OUT = {1: torch.uint8, 4: torch.int32, 8: torch.int64}
@@ -437,11 +447,9 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
     flags = torch.zeros(1, dtype=torch.int32, device=dev)
     _check(L.pg_lev_profile(_ptr(tokens), n, l, tokens.stride(0), _ptr(prof), np_, _ptr(lens), _ptr(flags), _stream()),
            "pg_lev_profile")
-    if int(flags.item()):
-        raise ValueError("levenshtein_knn: tokens must be 1..31 with zeros only as right padding")
     if l > 128:
         raise ValueError("levenshtein_knn: at most 128 tokens per sequence")
-    planes = pack(tokens, bits=BITS_5, width=128)            # chunk p of a record = bit plane p (128 bits)
+    planes = pack(tokens, bits=BITS_5, width=128, check=False)   # chunk p of a record = bit plane p (128 bits)
     counts = torch.empty(nrows, dtype=torch.int32, device=dev)
     symenv = os.environ.get("PG_EPS_SYM", "auto")            # the filter is symmetric like the eps graph
     sym = row0 == 0 and nrows == n and n < (1 << 24) and symenv != "0" and (symenv == "1" or n >= 32768)
@@ -455,11 +463,15 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
         if sym:
             _check(L.pg_lev_candidates_sym(_ptr(prof), np_, n, int(band), int(cap), _ptr(slot_idx), _ptr(slot_w),
                                            _ptr(slot_aux), _ptr(counts), _ptr(counts_lo), _stream()), "pg_lev_candidates_sym")
-            mx = int((counts + counts_lo).max().item())
+            tot = counts + counts_lo
         else:
             _check(L.pg_lev_candidates(_ptr(prof), np_, n, row0, nrows, int(band), int(cap), _ptr(slot_idx),
                                        _ptr(slot_w), _ptr(counts), _stream()), "pg_lev_candidates")
-            mx = int(counts.max().item())
+            tot = counts
+        # the ONE host sync of a step: the token check of the profile pass and the largest candidate count
+        bad, mx = (int(v) for v in torch.stack([(flags[0] | planes.flags[0]).to(torch.int64), tot.max().to(torch.int64)]).cpu())
+        if bad:
+            raise ValueError("levenshtein_knn: tokens must be 1..31 with zeros only as right padding")
         if mx <= cap:
             break
         cap = ((mx + 63) // 64) * 64          # some row has more candidates than slots: redo with room
