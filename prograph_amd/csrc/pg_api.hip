@@ -658,8 +658,9 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   if (ncols > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_knn_hamming: ncols exceeds 2^24");
   p.k = k; p.knnFirst = first; p.floorKeys = floor_keys; p.lastKeys = last_keys;
   // optimistic stage-1 cap (pg_nsq.h): 8 = half of what unrelated sequences show in the plane-0 bound
-  // (pg_mm.h: 6 - a tile of 1024 pairs is examined as soon as one pair passes, so false candidates cost more there)
-  p.knnGuess = getenv("PG_KNN_GUESS") ? (u32)atoi(getenv("PG_KNN_GUESS")) : (use_mm_engine(nrows) ? 6u : 8u);
+  // (pg_mm.h: 7 - a tile of 1024 pairs is examined as soon as one pair passes, so false candidates cost more there;
+  //  6 is 3 % faster on 256-member clusters but 30 % slower on 64-member ones: profiles/r02_engine_landscape.txt)
+  p.knnGuess = getenv("PG_KNN_GUESS") ? (u32)atoi(getenv("PG_KNN_GUESS")) : (use_mm_engine(nrows) ? 7u : 8u);
   if (p.filter == 0) p.knnGuess = 0;                       // no stage 1, nothing to cap
   p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;

@@ -82,11 +82,7 @@ __device__ __forceinline__ int pg_or16(const pg_v16i &d) {
 // Records of up to three chunks (L <= 64 with 5 bit planes): held at 4 waves per SIMD (the kNN instance
 // would take 141 VGPRs; pinned to 128 it spills 7 of them outside the loops, measured faster)
 template <class M, int MODE>
-#ifndef PG_X_NOATTR
 __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M::Q <= 3 ? 4 : 1, 8))) void pg_mm_kernel(const NsqParams p) {
-#else
-__global__ __launch_bounds__(PG_WG_THREADS) void pg_mm_kernel(const NsqParams p) {
-#endif
   constexpr int Q = M::Q;
   constexpr int C = Q <= 4 ? 2 : 1;                        // direct form: columns per lane
   constexpr int NP = PG_MM_NP;
