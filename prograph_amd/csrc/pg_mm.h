@@ -139,7 +139,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       basehi = (u32)((unsigned long long)b >> 32);
     }
     auto row_base = [&](int row) -> long long {
-      return (long long)(((unsigned long long)__builtin_amdgcn_readlane(basehi, row) << 32) | __builtin_amdgcn_readlane(baselo, row));
+      // (readlane returns a signed int: without the u32 casts a low half with bit 31 set sign-extends into the high half)
+      const u32 lo32 = (u32)__builtin_amdgcn_readlane((int)baselo, row), hi32 = (u32)__builtin_amdgcn_readlane((int)basehi, row);
+      return (long long)(((unsigned long long)hi32 << 32) | (unsigned long long)lo32);
     };
     const u32 G0 = (MODE == PG_MODE_KNN && canFilter) ? p.knnGuess : 0u;
     u32 failed = 0;                                         // kNN: rows that lost their optimistic cap (bit = row, all 32 bits in use)

@@ -768,3 +768,23 @@ def test_minkowski_f16_against_the_reference(nat):
             else:
                 assert np.array_equal(ip, g[f"{name}_{key}_indptr"]) and np.array_equal(ix, g[f"{name}_{key}_indices"])
                 assert np.array_equal(w.astype(np.float64), g[f"{name}_{key}_weights"].astype(np.float64))
+
+
+def test_eps_graph_with_more_than_2_31_entries(nat, engine):
+    """Every pair matches (eps >= L): nnz = N*(N-1) - duplicates > 2^31, so a row's place in the CSR needs all
+    64 bits (regression: the fill pass composed it from two v_readlane halves with a sign-extending low half).
+    Checked on the rows whose offsets lie beyond 2^31 and 2^32-adjacent boundaries, against numpy."""
+    N, L = 48_000, 4
+    rng = np.random.RandomState(9)
+    tok = rng.randint(0, 201, size=(N, L)).astype(np.uint8)
+    tok[N - 1] = tok[7]                                            # one duplicate pair: d == 0 is excluded
+    p = nat.pack(torch.from_numpy(tok), bits=8)
+    indptr, idx, w = nat.eps_graph(p, p, nat.CMP_LE, 4, cap=64)
+    torch.cuda.synchronize()
+    ip = indptr.cpu().numpy()
+    assert int(ip[-1]) == N * (N - 1) - 2 and int(ip[-1]) > 2 ** 31
+    for r in (0, 7, int(np.searchsorted(ip, 2 ** 31)) - 1, int(np.searchsorted(ip, 2 ** 31)), N - 2, N - 1):
+        d = (tok != tok[r]).sum(1)
+        cols = np.nonzero(d > 0)[0]
+        a, b = int(ip[r]), int(ip[r + 1])
+        assert np.array_equal(idx[a:b].cpu().numpy(), cols) and np.array_equal(w[a:b].cpu().numpy(), d[cols]), r

@@ -29,10 +29,22 @@ for it in range(iters):
     os.environ["PG_KNN_GUESS"] = str(rng.choice([0, 2, 5, 8, 8, 8, 20]))
     os.environ["PG_LB_FILTER"] = str(rng.choice([0, 1, 1, 1, 2]))
     os.environ["PG_EPS_SYM"] = "auto" if BIG else str(rng.choice([0, 1]))
-    p = nat.pack(torch.from_numpy(tok), bits=bits)
+    # both engines; on the MFMA engine also the density rules of its filter hierarchy (level-2 runs and direct
+    # runs start early / late / never) and the fill pass for overflowed rows (always / rarely)
+    os.environ["PG_ENGINE"] = str(rng.choice(["valu", "mfma", "mfma", "mfma"]))
+    os.environ["PG_MM_L1"] = str(rng.choice([1, 16, 96, 96, 200, 257]))
+    os.environ["PG_MM_L2"] = str(rng.choice([1, 8, 48, 48, 65]))
+    os.environ["PG_MM_RUN"] = str(rng.choice([1, 2, 8, 8, 64]))
+    os.environ["PG_FILL_MIN_ROWS"] = str(rng.choice([0, 8, 8, 1000000]))
     k = int(rng.choice([1, 5, 16, 40, 63, 90]))
     lo = int(rng.randint(0, N // 2)); nr = int(rng.randint(1, N - lo + 1)) if rng.rand() < 0.5 else None
     if nr is None: lo = 0
+    if os.environ.get("STRESS_ONLY") and int(os.environ["STRESS_ONLY"]) != it:      # replay one iteration of a run
+        rng.choice([1, 2, 3, 6, L // 2]); (rng.choice([0, 0, 1, 2, 3, 4]) if N <= 2500 else None); rng.choice([4, 64, 512])
+        continue
+    p = nat.pack(torch.from_numpy(tok), bits=bits)
+    if os.environ.get("STRESS_ONLY"):
+        print(f"replaying it={it}: N={N} L={L} bits={bits} k={k} row0={lo} nrows={nr} engine={os.environ['PG_ENGINE']}", flush=True)
     idx, d = nat.knn_graph(p, p, k, row0=lo, nrows=nr)
     ridx, rd = C.knn(tok, k, row0=lo, nrows=(N - lo if nr is None else nr))
     ok1 = np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
@@ -44,7 +56,8 @@ for it in range(iters):
     ok2 = np.array_equal(ip.cpu().numpy(), rip) and np.array_equal(ix.cpu().numpy(), rix) and np.array_equal(w.cpu().numpy(), rw)
     if not (ok1 and ok2):
         print(f"MISMATCH it={it} N={N} L={L} amax={amax} bits={bits} k={k} eps={eps} cmp={cmp} cap={cap} row0={lo} nrows={nr} "
-              f"guess={os.environ['PG_KNN_GUESS']} filter={os.environ['PG_LB_FILTER']} sym={os.environ['PG_EPS_SYM']} knn_ok={ok1} eps_ok={ok2}", flush=True)
+              f"guess={os.environ['PG_KNN_GUESS']} filter={os.environ['PG_LB_FILTER']} sym={os.environ['PG_EPS_SYM']} engine={os.environ['PG_ENGINE']} "
+              f"L1={os.environ['PG_MM_L1']} L2={os.environ['PG_MM_L2']} run={os.environ['PG_MM_RUN']} fill={os.environ['PG_FILL_MIN_ROWS']} knn_ok={ok1} eps_ok={ok2}", flush=True)
         sys.exit(1)
     if it % (2 if BIG else 20) == 0:
         print(f"it {it} ok ({time.time() - t0:.0f}s) N={N} L={L} bits={bits} k={k}", flush=True)
