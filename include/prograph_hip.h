@@ -26,11 +26,11 @@
  * zero).  A 64-lane wavefront that owns 64 consecutive sequences therefore reads one chunk per
  * lane as a single fully coalesced 1 KiB `global_load_dwordx4`, and the Hamming distance of
  * two records is B+1 VALU instructions per 32 tokens (xor, v_bitop3 x (B-1), v_bcnt).
- * Behind the Q chunk arrays the buffer carries four SIGNATURE SECTIONS (bit planes 0..3, 32 * Npad
- * bytes each): per sequence the 31-bit filter signature of that plane (XOR fold of its dwords)
- * expanded to one byte per bit, per 32 sequences one 1 KiB block in int8-MFMA fragment order - the
- * column operands of the matrix-core filter stages of the all-pairs engine (prograph_amd/csrc/pg_mm.h).
- * Buffer size: pg_planes_bytes(N, L, bits) = (pg_nchunks(L, bits) * 16 + 128) * pg_npad(N) bytes.
+ * Behind the Q chunk arrays the buffer carries the SIGNATURE SECTION (32 * Npad bytes): per sequence
+ * the 31-bit filter signature (XOR fold of its plane-0 dwords) expanded to one byte per bit, per 32
+ * sequences one 1 KiB block in int8-MFMA fragment order - the column operand of the matrix-core
+ * filter stage of the all-pairs engine (prograph_amd/csrc/pg_mm.h).
+ * Buffer size: pg_planes_bytes(N, L, bits) = (pg_nchunks(L, bits) * 16 + 32) * pg_npad(N) bytes.
  */
 #ifndef PROGRAPH_HIP_H
 #define PROGRAPH_HIP_H

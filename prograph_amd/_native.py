@@ -159,8 +159,8 @@ def nchunks(l, bits):
 
 
 def planes_bytes(n, l, bits):
-    """Chunk arrays + four signature sections of 32 bytes per sequence (MFMA column operands)."""
-    return (nchunks(l, bits) * 16 + 32 * 4) * npad(n)
+    """Chunk arrays + the signature section of 32 bytes per sequence (MFMA column operand)."""
+    return (nchunks(l, bits) * 16 + 32) * npad(n)
 
 
 class Planes:

@@ -505,7 +505,7 @@ static const nsq_fn kMm[8] = {pg_launch_mm_g1, pg_launch_mm_g2, pg_launch_mm_g3,
 // one pass of 32 rows per wave (PG_ROWS_PER_WAVE: whole passes)
 static void plan_mm(int64_t nrows, NsqParams *p, int *grid) {
   long long rpw = PG_MM_RB;
-  if (const char *e = getenv("PG_ROWS_PER_WAVE")) { if (atoi(e) > 0) rpw = (atoi(e) + PG_MM_RB - 1) / PG_MM_RB * PG_MM_RB; }
+  if (const char *e = getenv("PG_ROWS_PER_WAVE")) { if (atoi(e) > 0) rpw = atoi(e); }
   p->rowsPerWave = (int)rpw; p->rowsPerPass = PG_MM_RB;
   p->mmDenseL1 = getenv("PG_MM_L1") ? atoi(getenv("PG_MM_L1")) : PG_MM_DENSE_L1;
   p->mmDenseL2 = getenv("PG_MM_L2") ? atoi(getenv("PG_MM_L2")) : PG_MM_DENSE_L2;

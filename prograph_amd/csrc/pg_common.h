@@ -119,6 +119,7 @@ __device__ __forceinline__ u32 mismatch_lb(const uint4 &r0, const uint4 &c0, u32
 template <int G, int B>
 struct HammingMetric {
   static constexpr int Q = Rec<G, B>::Q;
+  static constexpr int kGroups = G, kBits = B;
   static constexpr bool kHasLB = true;
   static __device__ __forceinline__ u32 dist(const uint4 (&r)[Q], const uint4 (&c)[Q], u32 init) {
     return mismatch<G, B>(r, c, init);

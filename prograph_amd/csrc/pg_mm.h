@@ -47,12 +47,11 @@ typedef int pg_v16i __attribute__((ext_vector_type(16)));
 #define PG_MM_RB 32          // rows per pass = M of the MFMA tile
 #define PG_MM_QCAP 128       // candidate queue entries per wave: < 64 before a push, <= 64 per push
 #define PG_MM_ST 128         // columns per super-tile: 4 MFMA tiles = one direct-form tile (C = 2)
-#define PG_MM_NP 4           // bit planes with a signature section: level 2 of the filter uses planes 0..3 (each costs 4 VGPRs
-                             // of row operand; plane 4 of the 5-bit alphabet only separates tokens 16..20 from the rest)
-// defaults of the density rules (NsqParams carries them: PG_MM_L1 / PG_MM_L2 / PG_MM_RUN override for experiments)
-#define PG_MM_DENSE_L1 96    // of 256 lane slots per super-tile with a level-1 candidate: go to level 2
-#define PG_MM_DENSE_L2 48    // of 64 lane slots of the first tile still occupied at level 2: run direct
-#define PG_MM_DIRECT_RUN 8   // super-tiles of direct form before the filter is probed again
+#define PG_MM_NP 1           // bit planes with a signature section in the plane buffer (plane 0: the MFMA filter)
+// defaults of the density rules (NsqParams carries them: PG_MM_L1 / PG_MM_RUN override for experiments)
+#define PG_MM_DENSE_L1 96    // of 256 lane slots per super-tile with a candidate: leave the MFMA form
+#define PG_MM_DENSE_L2 48    // (unused since the MFMA level 2 was dropped; kept in NsqParams for A/B builds)
+#define PG_MM_DIRECT_RUN 8   // super-tiles of dense form before the MFMA filter is probed again
 
 static_assert(PG_MM_QCAP >= 63 + 64, "a register push adds up to 64 candidates to a queue holding up to 63");
 static_assert(PG_QCAP >= 63 + 4 * 2 * PG_PUSH_MAX, "pg_nsq.h kNN queue: a group pushes up to 4 rows x 2 columns x PG_PUSH_MAX");
@@ -85,13 +84,16 @@ template <class M, int MODE>
 __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M::Q <= 3 ? 4 : 1, 8))) void pg_mm_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
   constexpr int C = Q <= 4 ? 2 : 1;                        // direct form: columns per lane
-  constexpr int NP = PG_MM_NP;
   constexpr bool kEps = MODE != PG_MODE_KNN;
   constexpr bool kSym = MODE == PG_MODE_EPS_SYM;
   constexpr int RB = PG_MM_RB;
   constexpr int LROWS = MODE == PG_MODE_KNN ? RB : 1;
   __shared__ uint4 rowbuf[PG_WG_WAVES][RB][Q];
   __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
+  // dense runs: plane folds of the pass's rows, 8 words a row.  The kNN instance has no LDS to spare (its 40 KB
+  // put exactly four workgroups on a CU): there the folds live in lanes 56..63 of the row's list, which are
+  // free while the list ends below lane 56 (k <= 55; beyond, the dense runs stay in the exact form)
+  __shared__ uint4 rfbuf[PG_WG_WAVES][kEps ? RB : 1][2];
   __shared__ u32 cqbuf[PG_WG_WAVES][PG_MM_QCAP];           // deferred candidates: row << SH | column
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -101,7 +103,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   const long long wr1 = (wr0 + p.rowsPerWave < p.nrows) ? wr0 + p.rowsPerWave : p.nrows;
   const uint4 *__restrict__ colp = p.colPlanes;
   const pg_v4i *__restrict__ colsig = reinterpret_cast<const pg_v4i *>(p.colSig);
-  const long long sigStride = p.colNpad * 2;               // uint4 per plane section (32 bytes per sequence)
   const u32 ncols = (u32)p.ncols;
   const int nst = (int)((p.ncols + PG_MM_ST - 1) / PG_MM_ST);   // super-tiles of 128 columns
   const uint4 *rows = &rowbuf[wv][0][0] + opaque_zero();   // broadcast reads, kept "divergent"
@@ -154,24 +155,21 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- row operand of the level-1 MFMA: lane l holds row l & 31, plane-0 signature bits
-    // 16*(l >> 5) .. +15.  (The operands of planes 1.. are built when a level-2 run starts.) ----
-    auto row_operand = [&](int pl, u32 &pa) -> pg_v4i {
+    // ---- row operand of the MFMA: lane l holds row l & 31, signature bits 16*(l >> 5) .. +15 ----
+    u32 pa0;
+    pg_v4i A0;
+    {
       uint4 rec[Q];
 #pragma unroll
       for (int q = 0; q < Q; ++q) rec[q] = rowbuf[wv][lane & 31][q];
-      const u32 s31 = pg_sig31(M::fold_plane(rec, pl));
-      pa = (u32)__builtin_popcount(s31);
+      const u32 s31 = pg_sig31(M::fold(rec));
+      pa0 = (u32)__builtin_popcount(s31);
       const u32 half = (s31 >> (16 * (lane >> 5))) & 0xFFFFu;
-      pg_v4i a;
-      a[0] = (int)pg_expand_pm1(half);
-      a[1] = (int)pg_expand_pm1(half >> 4);
-      a[2] = (int)pg_expand_pm1(half >> 8);
-      a[3] = (int)pg_expand_pm1(half >> 12);
-      return a;
-    };
-    u32 pa0;
-    pg_v4i A0 = row_operand(0, pa0);
+      A0[0] = (int)pg_expand_pm1(half);
+      A0[1] = (int)pg_expand_pm1(half >> 4);
+      A0[2] = (int)pg_expand_pm1(half >> 8);
+      A0[3] = (int)pg_expand_pm1(half >> 12);
+    }
     // A row's bound: lanes 32.. hold it in boundv (authoritative) and, as pa - bound clamped to int8,
     // in the top byte of A0[3] (k = 31).  A bound beyond pa + 128 passes everything either way.
     u32 boundv = 0;
@@ -257,13 +255,13 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
             const int j = __builtin_ctzll(m);
             m &= m - 1;
             const u32 x = __builtin_amdgcn_readlane(key, j);
-            if (x < thr && !(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
+            if (x < thr && !(resweep && __builtin_amdgcn_ballot_w64(lst == x && lane <= thrLane))) {
               const u32 prev = wave_shr1(lst, 0u);
               lst = (lst <= x) ? lst : (prev > x ? prev : x);
               thr = __builtin_amdgcn_readlane(lst, thrLane);
             }
           } while (m);
-          lstbuf[wv][rr][lane] = lst;
+          if (lane <= thrLane) lstbuf[wv][rr][lane] = lst;  // (lanes 56.. may hold the row's plane folds)
           thrv = (lane == rr) ? thr : thrv;
           publish(rr, thr);
         }
@@ -300,10 +298,10 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           const u32 x = __builtin_amdgcn_readlane(key, j);
           if (p.floorKeys && x <= __builtin_amdgcn_readlane(floorv, row)) continue;   // continuation round
           u32 lst = lstbuf[wv][row][lane];
-          if (x < __builtin_amdgcn_readlane(lst, thrLane) && !(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
+          if (x < __builtin_amdgcn_readlane(lst, thrLane) && !(resweep && __builtin_amdgcn_ballot_w64(lst == x && lane <= thrLane))) {
             const u32 prev = wave_shr1(lst, 0u);
             lst = (lst <= x) ? lst : (prev > x ? prev : x);
-            lstbuf[wv][row][lane] = lst;
+            if (lane <= thrLane) lstbuf[wv][row][lane] = lst;
             PG_ST(8, 1);
             const u32 nthr = __builtin_amdgcn_readlane(lst, thrLane);
             thrv = (lane == row) ? nthr : thrv;
@@ -361,7 +359,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // queue the candidates (negative entries) of one tile's result registers
     // C/D layout of the 32x32 MFMA: register r, lane l -> row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31
     auto queue_from = [&](const pg_v16i &d, int tile) {
-      PG_ST(5, 1);
+      PG_ST(5, 0);
       const u32 ebase = ((4u * (u32)(lane >> 5)) << SH) | (u32)(tile * 32 + (lane & 31));
       int total = 0;
 #pragma unroll
@@ -403,7 +401,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     };
     pg_v4i ring[4];
     int ringS = -1;                                         // super-tile whose fragments the ring holds
-    // level 1 of one super-tile; returns true when level 1 is not selective here (nothing was queued)
+    // one super-tile in the MFMA form; returns true when the signature is not selective here (nothing was queued)
     auto sweep_mfma = [&](int S, int Snext) -> bool {
       if (ringS != S) {
 #pragma unroll
@@ -431,7 +429,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       const u64 m2 = __builtin_amdgcn_ballot_w64(a2 < 0), m3 = __builtin_amdgcn_ballot_w64(a3 < 0);
       u32 tm = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
       const int nslots = (int)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
-      if (nslots >= p.mmDenseL1) return true;               // most lane slots hold a candidate: level 2 takes over
+      if (nslots >= p.mmDenseL1) return true;               // most lane slots hold a candidate: the dense form takes over
       while (tm) {                                          // ascending tiles: queue order = column order per row
         const int i = __builtin_ctz(tm);
         tm &= tm - 1;
@@ -442,83 +440,157 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       return false;
     };
 
-    // ---- level 2: a run of super-tiles [S0, S1) with the signatures of planes 0..NP-1, one MFMA per
-    // plane and tile, the sign bits AND-ed (a pair can only be within the bound if it is within it in
-    // every plane).  The next tile's NP fragments are in flight while a tile is evaluated.  Returns the
-    // super-tile it stopped at: S1, or S0 when the run's first tile is dense at this level too (the
-    // caller then runs the direct form). ----
-    auto load_frags = [&](pg_v4i (&dst)[NP], int tile) {
-      const pg_v4i *src = colsig + (long long)tile * 64 + lane;
+    // ---- dense forms (the signature is not selective: mutant libraries, one cluster) ----
+    //  exact : the round-1 direct form - the records of 64*C columns per lane in registers (two sets, the
+    //          next tile's loads in flight), every distance of every row-step, in-place epilogue
+    //  folded: per lane the PLANE FOLDS of four columns (256 columns a tile, B words a column: the G group
+    //          words of a plane XOR-ed into one); popcount(OR_p(fold_p(row) ^ fold_p(col))) <= d - an exact
+    //          test of "differs nowhere" per folded position, B + 1 ops a column whatever L is.  Rows go four
+    //          to a group of straight-line code (row folds from LDS as broadcast reads, the negated bound
+    //          seeds the popcount: one sign test and ONE branch a group); a row-step that passes reloads the
+    //          column records from L2 and takes the exact path.  The next tile's records are loaded one
+    //          64-column slice at a time between the groups and folded as they arrive.
+    // A run starts in the folded form and falls back to `exact` while more than half of the row-steps pass
+    // (bounds still loose, or eps graphs of data this dense), probing again every 16 super-tiles.
+    constexpr int G = M::kGroups, B = M::kBits;
+    constexpr int CF = 4;                                   // folded form: columns per lane
+    auto fold_rec = [&](const uint4 (&rec)[Q], u32 (&f)[B]) {
+      u32 w[4 * Q];
+      unpack<Q>(rec, w);
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) dst[pl] = src[pl * sigStride];
-    };
-    auto tile_level2 = [&](const pg_v4i (&Ax)[NP], const pg_v4i (&b)[NP], int tile, bool probe) -> bool {
-      pg_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, b[0], zero16, 0, 0, 0);
+      for (int pl = 0; pl < B; ++pl) {
+        f[pl] = w[pl * G];
 #pragma unroll
-      for (int pl = 1; pl < NP; ++pl) {                     // one plane at a time: two result sets live, not NP
-        __builtin_amdgcn_sched_barrier(0);
-        const pg_v16i t = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ax[pl], b[pl], zero16, 0, 0, 0);
-        d &= t;                                             // AND of the signs
-        asm volatile("" : "+v"(d));                         // keeps the chain sequential (no tree of result sets)
+        for (int g = 1; g < G; ++g) f[pl] ^= w[pl * G + g];
       }
-      __builtin_amdgcn_sched_barrier(0);
-      const u64 slots = __builtin_amdgcn_ballot_w64(pg_or16(d) < 0);
-      if (!slots) return false;
-      if (probe && __builtin_popcount((u32)slots) + __builtin_popcount((u32)(slots >> 32)) >= p.mmDenseL2) return true;
-      queue_from(d, tile);
-      return false;
     };
-
-    // ---- direct form: whole column records in registers (two register sets, the next tile's loads in
-    // flight), every exact distance, one min + compare + branch per row-step ----
-    auto row_direct = [&](const uint4 (&c)[C][Q], const uint4 &r0, int rr, u32 col0) {
-      if constexpr (MODE == PG_MODE_KNN) {
-        if (resweep && !((failed >> rr) & 1u)) return;      // phase 1: frozen rows are final
+    auto fold_rows = [&]() {                                // the pass's row folds -> LDS (lane r < 32: row r)
+      uint4 rec[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) rec[q] = rowbuf[wv][lane & 31][q];
+      u32 f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      u32 fb[B];
+      fold_rec(rec, fb);
+#pragma unroll
+      for (int pl = 0; pl < B; ++pl) f[pl] = fb[pl];
+      if (lane < RB) {
+        uint4 *dst = kEps ? &rfbuf[wv][kEps ? lane : 0][0] : reinterpret_cast<uint4 *>(&lstbuf[wv][kEps ? 0 : lane][56]);
+        dst[0] = make_uint4(f[0], f[1], f[2], f[3]);
+        dst[1] = make_uint4(f[4], f[5], f[6], f[7]);
       }
+    };
+    constexpr int RFS = kEps ? 2 : 16;                      // uint4 stride between two rows' folds
+    const uint4 *rfold = (kEps ? &rfbuf[wv][0][0] : reinterpret_cast<const uint4 *>(&lstbuf[wv][0][56])) + opaque_zero();
+    // lane r: minus the bound of row r for the dense forms (pairs at or beyond it cannot matter); 0 = nothing
+    // can: rows past nr and, in phase 1, the frozen rows (their lists are final)
+    auto neg_bounds = [&]() -> u32 {
+      if constexpr (kEps) return lane < nr ? 0u - p.hi1 : 0u;
+      const u32 t = thrv >> 24;                             // open lists read 255
+      const bool live = lane < nr && (!resweep || ((failed >> (lane & 31)) & 1u));
+      return live ? 0u - ((t < capv ? t : capv) + resweep) : 0u;
+    };
+    auto load_rec = [&](uint4 (&dst)[Q], long long col) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) dst[q] = colp[(long long)q * p.colNpad + col];
+    };
+    // exact distances of one row-step + the in-place epilogue (the round-1 direct form)
+    auto row_exact = [&](const uint4 (&c)[C][Q], int rr, u32 col0, u32 bound) {
       uint4 r[Q];
-      r[0] = r0;
 #pragma unroll
-      for (int q = 1; q < Q; ++q) r[q] = rows[rr * Q + q];
+      for (int q = 0; q < Q; ++q) r[q] = rows[rr * Q + q];
       u32 d[C];
 #pragma unroll
       for (int b = 0; b < C; ++b) d[b] = M::dist(r, c[b], bias);
       u32 dmin = d[0];
 #pragma unroll
       for (int b = 1; b < C; ++b) dmin = dmin < d[b] ? dmin : d[b];
-      const u32 bound = kEps ? p.span + 1u : (__builtin_amdgcn_readlane(thrv, rr) >> 24) + resweep;
       if (__builtin_amdgcn_ballot_w64(dmin < bound)) {
 #pragma unroll
         for (int b = 0; b < C; ++b) epilogue(d[b], col0 + b * 64, rr);
       }
     };
-    auto load_cols = [&](uint4 (&dst)[C][Q], int dt) {     // direct tile dt: columns dt * 64 * C ..
+    auto load_cols = [&](uint4 (&dst)[C][Q], int dt) {     // exact tile dt: columns dt * 64 * C ..
 #pragma unroll
-      for (int b = 0; b < C; ++b)
-#pragma unroll
-        for (int q = 0; q < Q; ++q) dst[b][q] = colp[(long long)q * p.colNpad + (long long)dt * (64 * C) + b * 64 + lane];
+      for (int b = 0; b < C; ++b) load_rec(dst[b], (long long)dt * (64 * C) + b * 64 + lane);
     };
-    auto rows_direct = [&](const uint4 (&c)[C][Q], int dt) {
+    auto rows_exact = [&](const uint4 (&c)[C][Q], int dt) {
+      PG_ST(2, 1);
       const u32 col0 = (u32)(dt * (64 * C)) + lane;
-      uint4 ra = rows[0], rb = rows[Q];
-      for (int rr = 0; rr < nr; rr += 2) {
-        row_direct(c, ra, rr, col0);
-        ra = rows[(rr + 2 < RB ? rr + 2 : RB - 1) * Q];
-        if (rr + 1 < nr) row_direct(c, rb, rr + 1, col0);
-        rb = rows[(rr + 3 < RB ? rr + 3 : RB - 1) * Q];
+      const u32 nbv = neg_bounds();                         // a row's bound only matters before its own step
+      for (int rr = 0; rr < nr; ++rr) {
+        const u32 bnd = 0u - (u32)__builtin_amdgcn_readlane((int)nbv, rr);
+        if (bnd) row_exact(c, rr, col0, kEps ? p.span + 1u : bnd);
       }
+    };
+    // one folded tile: 256 columns from colbase, folds in cf; while it runs, the next tile's slices are
+    // loaded and folded into cfn (more = there is one).  Returns the row-steps that passed the bound.
+    auto tile_folded = [&](const u32 (&cf)[CF][B], u32 (&cfn)[CF][B], long long colbase, bool more) -> int {
+      PG_ST(11, 1);
+      u32 pend = 0;                                         // rows with a column inside their bound
+      const u32 nbv = neg_bounds();
+      uint4 nx[Q];
+#pragma unroll
+      for (int part = 0; part < CF; ++part) {
+        if (more) load_rec(nx, colbase + 64 * CF + part * 64 + lane);
+        for (int r0 = part * (RB / CF); r0 < (part + 1) * (RB / CF) && r0 < nr; r0 += 4) {
+          u32 sg[4];
+          u32 any = 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint4 f0 = rfold[(r0 + u) * RFS];
+            u32 rf[8] = {f0.x, f0.y, f0.z, f0.w, 0, 0, 0, 0};
+            if constexpr (B > 4) {
+              const uint4 f1 = rfold[(r0 + u) * RFS + 1];
+              rf[4] = f1.x; rf[5] = f1.y; rf[6] = f1.z; rf[7] = f1.w;
+            }
+            const u32 nb = (u32)__builtin_amdgcn_readlane((int)nbv, r0 + u);
+            sg[u] = 0;
+#pragma unroll
+            for (int b = 0; b < CF; ++b) {
+              u32 t = rf[0] ^ cf[b][0];
+#pragma unroll
+              for (int pl = 1; pl < B; ++pl) t = __builtin_amdgcn_bitop3_b32(rf[pl], cf[b][pl], t, PG_BITOP_XOR_OR);
+              sg[u] |= (u32)__builtin_popcount(t) + nb;     // lb - bound: negative = may be within the bound
+            }
+            any |= sg[u];
+          }
+          if (__builtin_amdgcn_ballot_w64((int)any < 0)) {  // rare once the bounds are tight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pend |= __builtin_amdgcn_ballot_w64((int)sg[u] < 0) ? 1u << (r0 + u) : 0u;
+          }
+        }
+        if (more) fold_rec(nx, cfn[part]);
+      }
+      // the row-steps that passed: records back from L2, exact distances, epilogue (one code site; a row's
+      // columns stay in ascending order)
+      const int passed = __builtin_popcount(pend);
+      PG_ST(5, passed);
+      while (pend) {
+        const int rr = __builtin_ctz(pend);
+        pend &= pend - 1;
+        const u32 bnd = 0u - (u32)__builtin_amdgcn_readlane((int)nbv, rr);
+        for (int h = 0; h < CF / C; ++h) {
+          uint4 c[C][Q];
+#pragma unroll
+          for (int b = 0; b < C; ++b) load_rec(c[b], colbase + (h * C + b) * 64 + lane);
+          row_exact(c, rr, (u32)colbase + h * C * 64 + lane, kEps ? p.span + 1u : bnd);
+        }
+      }
+      return passed;
     };
 
     // kNN checkpoints (first super-tile after them): after 1/32 of the sweep a row without any near
     // column yet is taken to be unclustered and loses the cap; after 1/8 every row whose list is
     // not settled below G0 does.  Phase 1 covers the larger range in use.
-    auto checkpoint = [&](int snext) {
+    auto checkpoint = [&](int sprev, int snext) {            // the sweep went from super-tile sprev to snext
       if constexpr (MODE == PG_MODE_KNN) {
         const int sw1 = (nst + 31) >> 5, sw2 = (nst + 7) >> 3;
-        if (G0 && !resweep && (snext == sw1 || snext == sw2)) {
+        const bool at1 = sprev < sw1 && sw1 <= snext, at2 = sprev < sw2 && sw2 <= snext;
+        if (G0 && !resweep && (at1 || at2)) {
           while (qn > 0) flush();
           const bool mine = lane < nr && !((failed >> (lane & 31)) & 1);
           u32 dref = thrv >> 24;                             // open lists read 255
-          if (snext != sw2) dref = mine ? lstbuf[wv][lane & 31][p.knnFirst] >> 24 : 0u;
+          if (!at2) dref = mine ? lstbuf[wv][lane & 31][p.knnFirst] >> 24 : 0u;
           const bool late = mine && dref >= G0;
           const u32 now = (u32)__builtin_amdgcn_ballot_w64(late);   // rows < 32
           if (now) {
@@ -531,62 +603,64 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         }
       }
     };
-    auto run_direct = [&](int S0, int S1) {                 // super-tiles [S0, S1)
+    const bool canFold = p.filter != 0 && (kEps || thrLane < 56);   // PG_LB_FILTER=0: the exact form throughout
+    bool prefilter = canFold;
+    int exact_left = 0;
+    auto run_dense = [&](int S0, int S1) -> int {           // super-tiles [S0, S1); returns where it stopped (>= S1)
       while (qn > 0) flush();                               // in-place results must come after queued ones
-      constexpr int F = PG_MM_ST / (64 * C);                // direct tiles per super-tile
-      const int t0 = S0 * F, t1 = S1 * F;
-      uint4 ca[C][Q], cb[C][Q];
-      load_cols(ca, t0);
-      for (int dt = t0; dt < t1; dt += 2) {
-        load_cols(cb, dt + 1 < t1 ? dt + 1 : dt);
-        rows_direct(ca, dt);
-        if ((dt + 1) % F == 0) checkpoint((dt + 1) / F);
-        if (dt + 1 < t1) {
-          load_cols(ca, dt + 2 < t1 ? dt + 2 : dt + 1);
-          rows_direct(cb, dt + 1);
-          if ((dt + 2) % F == 0) checkpoint((dt + 2) / F);
+      if (canFold) fold_rows();
+      constexpr int F = PG_MM_ST / (64 * C);                // exact tiles per super-tile
+      int s = S0;
+      while (s < S1) {
+        if (prefilter && !(s & 1)) {
+          // folded tiles of two super-tiles each while the bound stays selective
+          u32 cf[CF][B], cfn[CF][B];
+          {
+            uint4 nx[Q];
+#pragma unroll
+            for (int b = 0; b < CF; ++b) { load_rec(nx, (long long)s * PG_MM_ST + b * 64 + lane); fold_rec(nx, cf[b]); }
+          }
+          while (s < S1) {
+            const bool more = s + 2 < S1;
+            const int passed = tile_folded(cf, cfn, (long long)s * PG_MM_ST, more);
+            s += 2;
+            checkpoint(s - 2, s);
+            if (passed * 2 > nr) { prefilter = false; exact_left = 16; break; }
+#pragma unroll
+            for (int b = 0; b < CF; ++b)
+#pragma unroll
+              for (int pl = 0; pl < B; ++pl) cf[b][pl] = cfn[b][pl];
+          }
+        } else {
+          // exact form: to the end of the run, or until the bound is due for another probe
+          int s1 = S1;
+          if (prefilter) s1 = s + 1;                        // an odd super-tile in front of the folded tiles
+          else if (canFold && s + exact_left < S1) s1 = s + exact_left;
+          const int t0 = s * F, t1 = s1 * F;
+          uint4 ca[C][Q], cb[C][Q];
+          load_cols(ca, t0);
+          for (int dt = t0; dt < t1; dt += 2) {
+            load_cols(cb, dt + 1 < t1 ? dt + 1 : dt);
+            rows_exact(ca, dt);
+            if ((dt + 1) % F == 0) checkpoint((dt + 1) / F - 1, (dt + 1) / F);
+            if (dt + 1 < t1) {
+              load_cols(ca, dt + 2 < t1 ? dt + 2 : dt + 1);
+              rows_exact(cb, dt + 1);
+              if ((dt + 2) % F == 0) checkpoint((dt + 2) / F - 1, (dt + 2) / F);
+            }
+          }
+          if (!prefilter && canFold) {
+            exact_left -= s1 - s;
+            if (exact_left <= 0) prefilter = true;
+          }
+          s = s1;
         }
       }
-    };
-
-    auto run_level2 = [&](int S0, int S1) -> int {
-      // row operands of planes 1..NP-1, built per run from the rows in LDS (a run is >= 32 tiles of
-      // NP MFMAs: the ~25 VALU instructions per plane do not show, and 4 VGPRs per plane stay free
-      // everywhere else); their bias bytes follow boundv, which only level 1 keeps current
-      pg_v4i Ax[NP];
-      u32 pax[NP];
-      Ax[0] = A0;
-      pax[0] = pa0;
-#pragma unroll
-      for (int pl = 1; pl < NP; ++pl) Ax[pl] = row_operand(pl, pax[pl]);
-      auto refresh = [&]() {
-#pragma unroll
-        for (int pl = 1; pl < NP; ++pl) {
-          const u32 nb = ((u32)Ax[pl][3] & 0x00FFFFFFu) | bias_byte(pax[pl], boundv);
-          Ax[pl][3] = (lane >= 32) ? (int)nb : Ax[pl][3];
-        }
-      };
-      refresh();
-      const int t0 = S0 * 4, t1 = S1 * 4;
-      pg_v4i bc[NP], bn[NP];                                // this tile's fragments, the next tile's (in flight)
-      load_frags(bc, t0);
-#pragma unroll 1
-      for (int t = t0; t < t1; ++t) {
-        load_frags(bn, t + 1 < t1 ? t + 1 : t);
-        if (tile_level2(Ax, bc, t, t == t0 && p.filter != 2)) return S0;   // filter == 2: never leave the filtered form (tests)
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) bc[pl] = bn[pl];
-        if (((t + 1) & 3) == 0) {
-          PG_ST(2, 1);
-          checkpoint((t + 1) >> 2);
-          refresh();                                        // a checkpoint may have LOOSENED bounds (cap removed)
-        }
-      }
-      return S1;
+      return s;
     };
 
     int send = nst;
-    int drun = p.mmDirectRun;                               // super-tiles per level-2 / direct run
+    int drun = p.mmDirectRun;                               // super-tiles per dense run
     const int sbeg = kSym ? (int)(pr0 / PG_MM_ST) : 0;     // EPS_SYM: from the super-tile that holds the pass's first row
     for (;;) {
       int S = sbeg;
@@ -594,18 +668,16 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         bool direct = !canFilter;
         int S1 = send;
         if (canFilter) {
-          if (!sweep_mfma(S, S + 1 < send ? S + 1 : S)) {   // the common case: level 1 did the super-tile
-            checkpoint(S + 1);
+          if (!sweep_mfma(S, S + 1 < send ? S + 1 : S)) {   // the common case: the MFMA form did the super-tile
+            checkpoint(S, S + 1);
             ++S;
+            drun = p.mmDirectRun;
             continue;
           }
-          // level 1 is not selective here: a run at level 2, or direct when that is dense as well
+          // the signature is not selective here: a run of the dense form
           S1 = S + drun < send ? S + drun : send;
-          const int stop = run_level2(S, S1);               // checkpoints inside
-          direct = stop == S;
-          // direct runs back off (8, 16, .. 64 super-tiles) while every probe finds level 2 dense as well
-          drun = direct ? (drun * 2 < 8 * p.mmDirectRun ? drun * 2 : 8 * p.mmDirectRun) : p.mmDirectRun;
-          S = stop;
+          direct = true;
+          drun = drun * 2 < 8 * p.mmDirectRun ? drun * 2 : 8 * p.mmDirectRun;   // back off while every probe is dense
           ringS = -1;                                       // the fragments prefetched before the run are stale:
 #pragma unroll
           for (int i = 0; i < 4; ++i) ring[i] = pg_v4i{0, 0, 0, 0};   // dead across the run (frees their registers there)
@@ -613,8 +685,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         if (direct) {
           PG_ST(3, 1);
           PG_ST(4, S1 - S);
-          run_direct(S, S1);                                // checkpoints inside
-          S = S1;
+          S = run_dense(S, S1);                             // checkpoints inside; a folded tile may end one past S1
         }
       }
       while (qn > 0) flush();

@@ -324,7 +324,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
       u32 dmin = d[0];
 #pragma unroll
       for (int b = 1; b < C; ++b) dmin = dmin < d[b] ? dmin : d[b];
-      const u32 bound = kEps ? p.span + 1u : (__builtin_amdgcn_readlane(thrv, rr) >> 24);
+      const u32 bound = kEps ? p.span + 1u : ((u32)__builtin_amdgcn_readlane((int)thrv, rr) >> 24);   // (u32: readlane returns a signed int)
       if (__builtin_amdgcn_ballot_w64(dmin < bound)) {
 #pragma unroll
         for (int b = 0; b < C; ++b) epilogue(d[b], col0 + b * 64, rr);

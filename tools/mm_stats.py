@@ -9,8 +9,8 @@ os.environ["PG_ENGINE"] = "mfma"
 import numpy as np, torch
 from prograph_amd import _native as nat, synth
 
-NAMES = ["L1 super-tiles", "with candidates", "escalated to L2", "L2-dense (direct runs)", "direct super-tiles", "tiles queued from",
-         "candidates queued", "flushes", "insertions/matches", "resweep super-tiles", "passes", "-"]
+NAMES = ["L1 super-tiles", "with candidates", "dense tiles, every distance", "dense runs", "dense super-tiles", "dense row-steps past the bound",
+         "candidates queued", "flushes", "insertions/matches", "resweep super-tiles", "passes", "dense tiles, folded bound"]
 lib = nat.lib()
 def stats(reset=True):
     buf = (ctypes.c_ulonglong * 12)()
