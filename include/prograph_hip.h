@@ -29,8 +29,11 @@
  * Behind the Q chunk arrays the buffer carries the SIGNATURE SECTION (32 * Npad bytes): per sequence
  * the 31-bit filter signature (XOR fold of its plane-0 dwords) expanded to one byte per bit, per 32
  * sequences one 1 KiB block in int8-MFMA fragment order - the column operand of the matrix-core
- * filter stage of the all-pairs engine (prograph_amd/csrc/pg_mm.h).
- * Buffer size: pg_planes_bytes(N, L, bits) = (pg_nchunks(L, bits) * 16 + 32) * pg_npad(N) bytes.
+ * filter stage of the all-pairs engine (prograph_amd/csrc/pg_mm.h) - and behind it the FOLD SECTION
+ * (32 * Npad bytes): two 16-byte arrays of Npad entries with the sequence's plane folds (plane p's G
+ * dwords XOR-ed into one), planes 0..3 and 4..7 (unused planes zero) - the operands of the engine's
+ * folded-exact bound on dense data.  pg_pack_planes writes all three parts.
+ * Buffer size: pg_planes_bytes(N, L, bits) = (pg_nchunks(L, bits) * 16 + 64) * pg_npad(N) bytes.
  */
 #ifndef PROGRAPH_HIP_H
 #define PROGRAPH_HIP_H
@@ -41,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 2   /* 2: plane buffers carry the signature section */
+#define PG_ABI_VERSION 2   /* 2: plane buffers carry the signature and fold sections */
 
 /* library error codes (negative return values) */
 #define PG_E_BADARG   (-1)   /* NULL pointer, negative size, k out of range ...        */

@@ -159,8 +159,8 @@ def nchunks(l, bits):
 
 
 def planes_bytes(n, l, bits):
-    """Chunk arrays + the signature section of 32 bytes per sequence (MFMA column operand)."""
-    return (nchunks(l, bits) * 16 + 32) * npad(n)
+    """Chunk arrays + 64 bytes per sequence: signature section (MFMA column operand) + fold section."""
+    return (nchunks(l, bits) * 16 + 64) * npad(n)
 
 
 class Planes:

@@ -70,7 +70,7 @@ int pg_device_info(int *cus, int *wave, char *arch, int arch_len) {
 int64_t pg_npad(int64_t n) { return n <= 0 ? 256 : ((n + 255) / 256) * 256; }
 int pg_ngroups(int l) { return l <= 0 ? 1 : (l + 31) / 32; }
 int pg_nchunks(int l, int bits) { return (pg_ngroups(l) * bits + 3) / 4; }
-int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunks(l, bits) * 16 + 32 * PG_MM_NP) * pg_npad(n); }
+int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunks(l, bits) * 16 + PG_AUX_BYTES) * pg_npad(n); }
 
 }  // extern "C"
 
@@ -85,9 +85,7 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
   if (s >= npad) return;
   const T *row = nullptr;
   if (s < n) row = src + (rows ? rows[s] : s) * ld;
-  u32 bad = 0, sig[PG_MM_NP];
-#pragma unroll
-  for (int p = 0; p < PG_MM_NP; ++p) sig[p] = 0;
+  u32 bad = 0, fold[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int g = 0; g < ng; ++g) {
     u32 pl[B];
 #pragma unroll
@@ -104,7 +102,7 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
       }
     }
 #pragma unroll
-    for (int p = 0; p < PG_MM_NP; ++p) sig[p] ^= pl[p];   // filter signatures: XOR fold of each plane's words
+    for (int p = 0; p < B; ++p) fold[p] ^= pl[p];         // plane folds: XOR of each plane's group words
 #pragma unroll
     for (int p = 0; p < B; ++p) {
       const int w = p * ng + g;               // plane-major record order
@@ -112,18 +110,24 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
     }
   }
   for (int w = ng * B; w < nq * 4; ++w) planes[((long long)(w >> 2) * npad + s) * 4 + (w & 3)] = 0;
-  // Signature sections (after the nq chunk arrays, one per bit plane 0..PG_MM_NP-1, 32 * npad bytes
-  // each): the column operands of the filter MFMAs (pg_mm.h), one byte per signature bit, per 32
+  // Signature section (after the nq chunk arrays, 32 * npad bytes): the column operands of the filter
+  // MFMAs (pg_mm.h) for the 31-bit signature of plane 0's fold, one byte per signature bit, per 32
   // sequences one 1 KiB block in fragment order: uint4 [tile][h * 32 + c] = bytes k = 16h .. 16h+15
   // of sequence 32 * tile + c; byte 31 is the constant 1 that multiplies the row's bias (0 for
   // padding sequences: they never pass).
-#pragma unroll
-  for (int p = 0; p < PG_MM_NP; ++p) {
-    const u32 s31 = pg_sig31(sig[p]);
-    uint4 *e = reinterpret_cast<uint4 *>(planes + (long long)nq * npad * 4) + (long long)p * npad * 2 + (s >> 5) * 64 + (s & 31);
+  {
+    const u32 s31 = pg_sig31(fold[0]);
+    uint4 *e = reinterpret_cast<uint4 *>(planes + (long long)nq * npad * 4) + (s >> 5) * 64 + (s & 31);
     e[0] = make_uint4(pg_spread4(s31), pg_spread4(s31 >> 4), pg_spread4(s31 >> 8), pg_spread4(s31 >> 12));
     e[32] = make_uint4(pg_spread4(s31 >> 16), pg_spread4(s31 >> 20), pg_spread4(s31 >> 24),
                        pg_spread4(s31 >> 28) | (row ? 0x01000000u : 0u));
+  }
+  // Fold section (after the signatures, 32 * npad bytes): two uint4 arrays, planes 0..3 and 4..7 of every
+  // sequence's plane folds (unused planes 0): the operands of the dense form's folded-exact bound.
+  {
+    uint4 *f = reinterpret_cast<uint4 *>(planes + (long long)nq * npad * 4) + npad * 2;
+    f[s] = make_uint4(fold[0], fold[1], fold[2], fold[3]);
+    f[npad + s] = make_uint4(fold[4], fold[5], fold[6], fold[7]);
   }
   if (bad) atomicOr(flags, bad);
 }
@@ -476,6 +480,8 @@ static int fill_nsq(NsqParams *p, const void *row_planes, int64_t row_npad, int6
   p->rowPlanes = (const uint4 *)row_planes; p->rowNpad = row_npad; p->row0 = row0; p->nrows = nrows;
   p->colPlanes = (const uint4 *)col_planes; p->colNpad = col_npad; p->ncols = ncols;
   p->colSig = p->colPlanes + (long long)pg_nchunks(l, bits) * col_npad;
+  p->colFold = p->colSig + 2 * col_npad;
+  p->rowFold = p->rowPlanes + ((long long)pg_nchunks(l, bits) + 2) * row_npad;
   return 0;
 }
 
@@ -488,25 +494,54 @@ static bool use_mm_engine(int64_t nrows) {
     if (!strcmp(e, "mfma")) return true;
     if (!strcmp(e, "valu")) return false;
   }
-  const long long thr = getenv("PG_ENGINE_MIN_ROWS") ? atoll(getenv("PG_ENGINE_MIN_ROWS")) : 65536;
+  const long long thr = getenv("PG_ENGINE_MIN_ROWS") ? atoll(getenv("PG_ENGINE_MIN_ROWS")) : 40000;   // tools/engine_crossover.py: kNN crosses at ~32k rows, eps at ~40k
   return nrows >= thr;
 }
 #ifdef PG_MM_STATS
 static unsigned long long *g_stats = nullptr;
-extern "C" int pg_debug_stats(unsigned long long *out12, int reset) {   // debug builds only (tools/mm_stats.py)
-  if (!g_stats) { if (hipMalloc(&g_stats, 16 * 8) != hipSuccess) return -1; hipMemset(g_stats, 0, 16 * 8); }
-  if (out12) { hipDeviceSynchronize(); hipMemcpy(out12, g_stats, 12 * 8, hipMemcpyDeviceToHost); }
-  if (reset) hipMemset(g_stats, 0, 16 * 8);
+extern "C" int pg_debug_stats(unsigned long long *out12, int reset) {   // debug builds only (tools/mm_stats.py); 16 counters
+  const size_t nst = 16 + 2 * 65536;                       // 16 counters, then (start, duration) of the first 65536 passes
+  if (!g_stats) { if (hipMalloc(&g_stats, nst * 8) != hipSuccess) return -1; hipMemset(g_stats, 0, nst * 8); }
+  if (out12) { hipDeviceSynchronize(); hipMemcpy(out12, g_stats, (reset & 2 ? nst : 16) * 8, hipMemcpyDeviceToHost); }
+  if (reset & 1) hipMemset(g_stats, 0, nst * 8);
   return 0;
 }
 #endif
 static const nsq_fn kMm[8] = {pg_launch_mm_g1, pg_launch_mm_g2, pg_launch_mm_g3, pg_launch_mm_g4,
                               pg_launch_mm_g5, pg_launch_mm_g6, pg_launch_mm_g7, pg_launch_mm_g8};
-// one pass of 32 rows per wave (PG_ROWS_PER_WAVE: whole passes)
+// One pass per wave.  A pass takes up to 32 rows (the M of the MFMA tile) and the CU holds 16 waves (four
+// workgroups: LDS and VGPR bound), so the grid runs in rounds of `slots` passes.  When 32-row passes would not
+// even fill one round, the rows are spread over ~97 % of the slots in smaller passes, down to 16 rows (N=50k L=32
+// kNN 1.03 -> 0.90 ms, N=100k L=128 2.40 -> 2.16 ms; tools/rows_sweep.py, profiles/r02_rows_per_pass.txt).
+// PG_MM_TAIL=1 also shrinks the passes of the LAST round of a longer grid (mmTailFrom / mmTailRows): measured
+// slower (dense 200k: 12.5 -> 14.1 ms, cfg3 3.81 -> 3.90) - a round of 2154 full passes on half-empty SIMDs runs
+// faster per pass than 3830 passes of 18 rows on full ones - and therefore off.
+// PG_ROWS_PER_WAVE = uniform passes of that many rows (tuning sweeps).
 static void plan_mm(int64_t nrows, NsqParams *p, int *grid) {
-  long long rpw = PG_MM_RB;
-  if (const char *e = getenv("PG_ROWS_PER_WAVE")) { if (atoi(e) > 0) rpw = atoi(e); }
+  long long rpw = PG_MM_RB, tailFrom = (nrows + PG_MM_RB - 1) / PG_MM_RB, tailRows = PG_MM_RB;
+  const long long slots = (long long)(cu_count() > 0 ? cu_count() : 256) * 16;
+  const char *e = getenv("PG_ROWS_PER_WAVE");
+  const char *t = getenv("PG_MM_TAIL");
+  if (e && atoi(e) > 0) {
+    rpw = atoi(e);
+    tailFrom = (nrows + rpw - 1) / rpw; tailRows = rpw;
+  } else {
+    const long long full = nrows / (slots * PG_MM_RB) * slots;          // passes of the full rounds
+    const long long rest = nrows - full * PG_MM_RB;
+    if (rest > 0 && (full == 0 || (t && atoi(t) == 1))) {
+      long long r = (long long)((double)rest / (0.97 * (double)slots)) + 1;
+      r = (r + 1) / 2 * 2;
+      if (r < 4) r = 4;
+      if (r > PG_MM_RB) r = PG_MM_RB;
+      if (full == 0 && r < 16) r = 16;                                  // a single round: at least half-filled MFMA tiles
+      tailFrom = full; tailRows = r;
+    }
+  }
   p->rowsPerWave = (int)rpw; p->rowsPerPass = PG_MM_RB;
+  p->mmTailFrom = tailFrom; p->mmTailRows = (int)tailRows;
+  const long long headRows = tailFrom * rpw < nrows ? tailFrom * rpw : nrows;
+  const long long waves = tailFrom + (nrows - headRows + tailRows - 1) / tailRows;
+  if (getenv("PG_DEBUG_PLAN")) fprintf(stderr, "[pg plan mm] rows=%lld: %lld passes of %lld rows + %lld of %lld\n", (long long)nrows, tailFrom, rpw, waves - tailFrom, tailRows);
   p->mmDenseL1 = getenv("PG_MM_L1") ? atoi(getenv("PG_MM_L1")) : PG_MM_DENSE_L1;
   p->mmDenseL2 = getenv("PG_MM_L2") ? atoi(getenv("PG_MM_L2")) : PG_MM_DENSE_L2;
   p->mmDirectRun = getenv("PG_MM_RUN") ? atoi(getenv("PG_MM_RUN")) : PG_MM_DIRECT_RUN;
@@ -515,7 +550,6 @@ static void plan_mm(int64_t nrows, NsqParams *p, int *grid) {
   if (!g_stats) pg_debug_stats(nullptr, 1);
   p->stats = g_stats;
 #endif
-  const long long waves = (nrows + rpw - 1) / rpw;
   *grid = (int)((waves + PG_WG_WAVES - 1) / PG_WG_WAVES);
 }
 

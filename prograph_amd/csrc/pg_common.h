@@ -9,6 +9,7 @@ typedef unsigned long long u64;
 #define PG_WAVE 64
 #define PG_WG_WAVES 4
 #define PG_WG_THREADS (PG_WAVE * PG_WG_WAVES)
+#define PG_AUX_BYTES 64   // per sequence after the chunk arrays: MFMA signature fragments (32 B) + plane folds (32 B)
 #define PG_RB 32    // rows per wave pass of the all-pairs engine (<= 64: per-row state is lane indexed)
 #define PG_RB_KNN 28 // kNN passes: 28 rows, so that lists + candidate queue keep 4 workgroups per CU in LDS
 #define PG_SORT_MAX 512 // symmetric eps: a row's back part (entries from lower rows) up to this size is rank-sorted in LDS
@@ -207,6 +208,16 @@ __device__ __forceinline__ u32 mask_rank(u64 m) {
 }
 
 // lane i <- lane i-1 (lane 0 <- `fill`) with one DPP move: wave_shr:1
+// OR of v over the wave; the result is valid in lane 63 (DPP row shifts, then row_bcast:15 / :31)
+__device__ __forceinline__ u32 wave_or_to63(u32 v) {
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8   -> lane 15 of a row: the row's OR
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+  return v;
+}
 __device__ __forceinline__ u32 wave_shr1(u32 v, u32 fill) {
   return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
 }
@@ -221,8 +232,11 @@ struct NsqParams {
   const uint4 *colPlanes;
   long long colNpad, ncols;
   unsigned long long *stats;   // debug builds (-DPG_MM_STATS): event counters of pg_mm_kernel, else unused
+  const uint4 *colFold, *rowFold;   // fold sections (two uint4 arrays of npad: planes 0..3, 4..7 of the plane folds)
   const uint4 *colSig;  // signature section of the column operand: MFMA B fragments, 1 KiB per 32 columns (pg_mm.h)
   int rowsPerWave, rowsPerPass;
+  long long mmTailFrom;   // pg_mm.h: waves from this index on take mmTailRows rows each (the last, partly filled round of the grid)
+  int mmTailRows;
   int mmDenseL1, mmDenseL2, mmDirectRun;   // pg_mm.h: density rules of the filter hierarchy
   int filter;   // 1 = plane-0 lower-bound filter allowed (adaptive per tile), 0 = always direct
   u32 knnGuess; // kNN: optimistic cap on the stage-1 bound until a row's list is full (0 = off), see pg_nsq.h

@@ -47,10 +47,10 @@ typedef int pg_v16i __attribute__((ext_vector_type(16)));
 #define PG_MM_RB 32          // rows per pass = M of the MFMA tile
 #define PG_MM_QCAP 128       // candidate queue entries per wave: < 64 before a push, <= 64 per push
 #define PG_MM_ST 128         // columns per super-tile: 4 MFMA tiles = one direct-form tile (C = 2)
-#define PG_MM_NP 1           // bit planes with a signature section in the plane buffer (plane 0: the MFMA filter)
 // defaults of the density rules (NsqParams carries them: PG_MM_L1 / PG_MM_RUN override for experiments)
-#define PG_MM_DENSE_L1 96    // of 256 lane slots per super-tile with a candidate: leave the MFMA form
+#define PG_MM_DENSE_L1 56    // of 256 lane slots per super-tile with a candidate: leave the MFMA form (tools/dense_knobs.py: 40..64 flat, 96 costs dense data 25 %)
 #define PG_MM_DENSE_L2 48    // (unused since the MFMA level 2 was dropped; kept in NsqParams for A/B builds)
+#define PG_MM_GROUP_ROWS 4    // folded form: rows per group (one sign test and one branch a group)
 #define PG_MM_DIRECT_RUN 8   // super-tiles of dense form before the MFMA filter is probed again
 
 static_assert(PG_MM_QCAP >= 63 + 64, "a register push adds up to 64 candidates to a queue holding up to 63");
@@ -90,17 +90,16 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   constexpr int LROWS = MODE == PG_MODE_KNN ? RB : 1;
   __shared__ uint4 rowbuf[PG_WG_WAVES][RB][Q];
   __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
-  // dense runs: plane folds of the pass's rows, 8 words a row.  The kNN instance has no LDS to spare (its 40 KB
-  // put exactly four workgroups on a CU): there the folds live in lanes 56..63 of the row's list, which are
-  // free while the list ends below lane 56 (k <= 55; beyond, the dense runs stay in the exact form)
-  __shared__ uint4 rfbuf[PG_WG_WAVES][kEps ? RB : 1][2];
   __shared__ u32 cqbuf[PG_WG_WAVES][PG_MM_QCAP];           // deferred candidates: row << SH | column
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
-  const long long wr0 = gw * p.rowsPerWave;
+  // the rows of this wave: rowsPerWave each, smaller shares (mmTailRows) in the last round of the grid
+  const bool tailWave = gw >= p.mmTailFrom;
+  const long long wrows = tailWave ? p.mmTailRows : p.rowsPerWave;
+  const long long wr0 = tailWave ? p.mmTailFrom * p.rowsPerWave + (gw - p.mmTailFrom) * p.mmTailRows : gw * p.rowsPerWave;
   if (wr0 >= p.nrows) return;   // whole wave leaves; no workgroup barrier is used below
-  const long long wr1 = (wr0 + p.rowsPerWave < p.nrows) ? wr0 + p.rowsPerWave : p.nrows;
+  const long long wr1 = (wr0 + wrows < p.nrows) ? wr0 + wrows : p.nrows;
   const uint4 *__restrict__ colp = p.colPlanes;
   const pg_v4i *__restrict__ colsig = reinterpret_cast<const pg_v4i *>(p.colSig);
   const u32 ncols = (u32)p.ncols;
@@ -111,31 +110,51 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   // eps entries carry the row in 5 bits above a 27-bit column; wider problems run the direct form
   const bool canFilter = p.filter != 0 && (!kEps || p.ncols < (1ll << 27));
   constexpr int SH = kEps ? 27 : 24;
+  // arguments that only cold code needs (staging a pass, storing results, the dense forms) are read from the
+  // kernel-argument segment where they are used: held in SGPRs across the sweep they crowd the loop state of
+  // the MFMA form out into spill lanes
+  typedef const NsqParams __attribute__((address_space(4))) *pg_kargs;
+  auto K = [&]() -> const NsqParams __attribute__((address_space(4))) & {
+    pg_kargs kp = (pg_kargs)__builtin_amdgcn_kernarg_segment_ptr();   // the kernel's one argument: NsqParams by value
+    asm volatile("" : "+s"(kp));                          // (opaque: not the values the prologue already loaded)
+    return *kp;
+  };
 
 #ifdef PG_MM_STATS
-  u32 st[12] = {0};   // 0 L1 super-tiles, 1 with candidates, 2 escalated to L2, 3 L2-dense (direct runs), 4 direct super-tiles,
+  u32 st[16] = {0};   // 12..15: kilo-cycles (s_memtime) of this wave in flush / in its insertion loop / in folded tiles / in passes
+  u32 st_unused[1] = {0};   // 0 L1 super-tiles, 1 with candidates, 2 escalated to L2, 3 L2-dense (direct runs), 4 direct super-tiles,
                       // 5 tiles queued from, 6 candidates queued, 7 flushes, 8 insertions / eps matches, 9 resweep super-tiles, 10 passes
 #define PG_ST(i, n) st[i] += (u32)(n)
+#define PG_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define PG_T1(i, v) st[i] += (u32)((__builtin_amdgcn_s_memtime() - v) >> 6)
 #else
 #define PG_ST(i, n)
+#define PG_T0(v)
+#define PG_T1(i, v)
 #endif
   for (long long pr0 = wr0; pr0 < wr1; pr0 += RB) {
     const long long left = wr1 - pr0;
     PG_ST(10, 1);
+    PG_T0(tp0);
+#ifdef PG_MM_STATS
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    const u32 st5_0 = st[5], st2_0 = st[2], st7_0 = st[7];
+#endif
     const int nr = __builtin_amdgcn_readfirstlane((int)(left < RB ? left : RB));
 
     // ---- stage the pass's rows into the wave's LDS region (wave private) ----
+    const auto &ka = K();
     for (int e = lane; e < RB * Q; e += 64) {
       const int rr = e % RB, q = e / RB;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (rr < nr) v = p.rowPlanes[(long long)q * p.rowNpad + p.row0 + (p.rowList ? p.rowList[pr0 + rr] : pr0 + rr)];
+      if (rr < nr) v = ka.rowPlanes[(long long)q * ka.rowNpad + ka.row0 + (ka.rowList ? ka.rowList[pr0 + rr] : pr0 + rr)];
       rowbuf[wv][rr][q] = v;
     }
     // eps: where row `lane` of the pass stores its matches: its slot, or (fill pass) its place in the CSR
     u32 baselo = 0, basehi = 0;
     if constexpr (kEps) {
       long long b = 0;
-      if (lane < nr) b = p.fillIndptr ? p.fillIndptr[p.rowList ? p.rowList[pr0 + lane] : pr0 + lane] : (pr0 + lane) * (long long)p.cap;
+      if (lane < nr) b = ka.fillIndptr ? ka.fillIndptr[ka.rowList ? ka.rowList[pr0 + lane] : pr0 + lane] : (pr0 + lane) * (long long)ka.cap;
       baselo = (u32)b;
       basehi = (u32)((unsigned long long)b >> 32);
     }
@@ -197,7 +216,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     u32 capv = G0 ? G0 : 255u;
     u32 floorv = 0u;                                        // kNN continuation rounds (k > 63)
     if constexpr (MODE == PG_MODE_KNN) {
-      if (p.floorKeys && lane < nr) floorv = p.floorKeys[pr0 + lane];
+      if (ka.floorKeys && lane < nr) floorv = ka.floorKeys[pr0 + lane];
     }
     const int thrLane = p.knnFirst + p.k - 1;               // last list lane that is still needed
     set_all_bounds(lane < nr ? (kEps ? p.hi1 : capv) : 0u); // rows past nr: bound 0, nothing passes
@@ -255,13 +274,13 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
             const int j = __builtin_ctzll(m);
             m &= m - 1;
             const u32 x = __builtin_amdgcn_readlane(key, j);
-            if (x < thr && !(resweep && __builtin_amdgcn_ballot_w64(lst == x && lane <= thrLane))) {
+            if (x < thr && !(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
               const u32 prev = wave_shr1(lst, 0u);
               lst = (lst <= x) ? lst : (prev > x ? prev : x);
               thr = __builtin_amdgcn_readlane(lst, thrLane);
             }
           } while (m);
-          if (lane <= thrLane) lstbuf[wv][rr][lane] = lst;  // (lanes 56.. may hold the row's plane folds)
+          lstbuf[wv][rr][lane] = lst;
           thrv = (lane == rr) ? thr : thrv;
           publish(rr, thr);
         }
@@ -273,6 +292,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     auto flush = [&]() {
       const int nbat = qn < 64 ? qn : 64;
       PG_ST(7, 1);
+      PG_T0(tf0);
       const u32 e = cq[lane];
       if constexpr (MODE == PG_MODE_KNN) {
         const u32 col = e & 0x00FFFFFFu;
@@ -291,6 +311,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         }
         const bool cand = act && key < thr;
         u64 m = __builtin_amdgcn_ballot_w64(cand);
+        PG_T0(ti0);
         while (m) {
           const int j = __builtin_ctzll(m);
           m &= m - 1;
@@ -298,16 +319,17 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           const u32 x = __builtin_amdgcn_readlane(key, j);
           if (p.floorKeys && x <= __builtin_amdgcn_readlane(floorv, row)) continue;   // continuation round
           u32 lst = lstbuf[wv][row][lane];
-          if (x < __builtin_amdgcn_readlane(lst, thrLane) && !(resweep && __builtin_amdgcn_ballot_w64(lst == x && lane <= thrLane))) {
+          if (x < __builtin_amdgcn_readlane(lst, thrLane) && !(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
             const u32 prev = wave_shr1(lst, 0u);
             lst = (lst <= x) ? lst : (prev > x ? prev : x);
-            if (lane <= thrLane) lstbuf[wv][row][lane] = lst;
+            lstbuf[wv][row][lane] = lst;
             PG_ST(8, 1);
             const u32 nthr = __builtin_amdgcn_readlane(lst, thrLane);
             thrv = (lane == row) ? nthr : thrv;
             publish(row, nthr);
           }
         }
+        PG_T1(13, ti0);
       } else {
         const u32 col = e & 0x07FFFFFFu;
         const u32 erow = e >> 27;
@@ -349,6 +371,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         cq[lane] = tail;
       }
       qn -= nbat;
+      PG_T1(12, tf0);
     };
 
     // ---- filtered form.  Hot path per super-tile: four level-1 MFMAs, the OR of each result, ONE
@@ -413,9 +436,11 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       pg_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[1], zero16, 0, 0, 0);
       ring[1] = nx[64];
       const int a0 = pg_or16(d0);
+      __builtin_amdgcn_sched_barrier(0);                    // two result sets in turn, not four (the 128-VGPR budget)
       d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[2], zero16, 0, 0, 0);
       ring[2] = nx[128];
       const int a1 = pg_or16(d1);
+      __builtin_amdgcn_sched_barrier(0);
       d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[3], zero16, 0, 0, 0);
       ring[3] = nx[192];
       const int a2 = pg_or16(d0);
@@ -454,33 +479,41 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // (bounds still loose, or eps graphs of data this dense), probing again every 16 super-tiles.
     constexpr int G = M::kGroups, B = M::kBits;
     constexpr int CF = 4;                                   // folded form: columns per lane
-    auto fold_rec = [&](const uint4 (&rec)[Q], u32 (&f)[B]) {
-      u32 w[4 * Q];
-      unpack<Q>(rec, w);
+    // plane folds of sequences come from the fold section of the plane buffer (pg_pack_planes): the columns'
+    // as per-lane loads (B words a column), the rows' as SCALAR loads - wave-uniform addresses in the
+    // constant address space, so a row's folds arrive in SGPRs and cost no VALU, LDS or VGPR at all.
+    // The section pointers are read from the kernel arguments again in every tile (K(), above).
+    typedef const u32 __attribute__((address_space(4))) *pg_kptr;
+    struct DenseArgs { pg_kptr rowA, rowB; const uint4 *colA, *colB; };
+    auto dense_args = [&]() -> DenseArgs {
+      const auto &k = K();
+      const uint4 *rf = k.rowFold, *cfp = k.colFold;
+      return DenseArgs{(pg_kptr)(unsigned long long)rf, (pg_kptr)(unsigned long long)(rf + k.rowNpad), cfp, cfp + k.colNpad};
+    };
+    u32 seqv;                                               // lane r: sequence index of pass row r (rows past nr: the last row's)
+    {
+      const long long i = pr0 + ((lane & 31) < nr ? (lane & 31) : nr - 1);
+      seqv = (u32)(ka.row0 + (ka.rowList ? ka.rowList[i] : i));
+    }
+    auto load_row_fold = [&](const DenseArgs &da, u32 (&f)[B], int rr) {
+      const unsigned long long sq = (u32)__builtin_amdgcn_readlane((int)seqv, rr < RB ? rr : RB - 1);
 #pragma unroll
-      for (int pl = 0; pl < B; ++pl) {
-        f[pl] = w[pl * G];
+      for (int pl = 0; pl < (B < 4 ? B : 4); ++pl) f[pl] = da.rowA[sq * 4 + pl];
 #pragma unroll
-        for (int g = 1; g < G; ++g) f[pl] ^= w[pl * G + g];
+      for (int pl = 4; pl < B; ++pl) f[pl] = da.rowB[sq * 4 + (pl - 4)];
+    };
+    auto load_col_fold = [&](const DenseArgs &da, u32 (&f)[B], long long col) {
+      const uint4 a = da.colA[col];
+      f[0] = a.x;
+      if constexpr (B > 1) f[1] = a.y;
+      if constexpr (B > 2) f[2] = a.z;
+      if constexpr (B > 3) f[3] = a.w;
+      if constexpr (B > 4) {
+        const u32 *hi = reinterpret_cast<const u32 *>(da.colB + col);
+#pragma unroll
+        for (int pl = 4; pl < B; ++pl) f[pl] = hi[pl - 4];
       }
     };
-    auto fold_rows = [&]() {                                // the pass's row folds -> LDS (lane r < 32: row r)
-      uint4 rec[Q];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) rec[q] = rowbuf[wv][lane & 31][q];
-      u32 f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      u32 fb[B];
-      fold_rec(rec, fb);
-#pragma unroll
-      for (int pl = 0; pl < B; ++pl) f[pl] = fb[pl];
-      if (lane < RB) {
-        uint4 *dst = kEps ? &rfbuf[wv][kEps ? lane : 0][0] : reinterpret_cast<uint4 *>(&lstbuf[wv][kEps ? 0 : lane][56]);
-        dst[0] = make_uint4(f[0], f[1], f[2], f[3]);
-        dst[1] = make_uint4(f[4], f[5], f[6], f[7]);
-      }
-    };
-    constexpr int RFS = kEps ? 2 : 16;                      // uint4 stride between two rows' folds
-    const uint4 *rfold = (kEps ? &rfbuf[wv][0][0] : reinterpret_cast<const uint4 *>(&lstbuf[wv][0][56])) + opaque_zero();
     // lane r: minus the bound of row r for the dense forms (pairs at or beyond it cannot matter); 0 = nothing
     // can: rows past nr and, in phase 1, the frozen rows (their lists are final)
     auto neg_bounds = [&]() -> u32 {
@@ -522,61 +555,100 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         if (bnd) row_exact(c, rr, col0, kEps ? p.span + 1u : bnd);
       }
     };
-    // one folded tile: 256 columns from colbase, folds in cf; while it runs, the next tile's slices are
-    // loaded and folded into cfn (more = there is one).  Returns the row-steps that passed the bound.
-    auto tile_folded = [&](const u32 (&cf)[CF][B], u32 (&cfn)[CF][B], long long colbase, bool more) -> int {
+    // one folded tile: 256 columns from colbase, folds in cf; the next tile's folds (from nxt) load into cfn
+    // meanwhile.  The rows go GR to a group of straight-line code, the next group's folds in flight; the sign of
+    // every lb - bound shifts into a per-slice hit mask (v_alignbit: one instruction a pair-of-64, no branch in
+    // the row loop).  After the rows the pairs inside the bound join the candidate queue of the MFMA form
+    // (exact distance from gathered records, 64 a batch).  Returns their number.
+    constexpr int GR = PG_MM_GROUP_ROWS;
+    auto tile_folded = [&](const u32 (&cf)[CF][B], u32 (&cfn)[CF][B], long long colbase, long long nxt) -> int {
       PG_ST(11, 1);
-      u32 pend = 0;                                         // rows with a column inside their bound
+      PG_T0(tt0);
+      const DenseArgs da = dense_args();
+#if defined(PG_DBG) && PG_DBG == 3
+      const u32 nbv = neg_bounds() & ((u32)p.filter >> 8);
+#else
       const u32 nbv = neg_bounds();
-      uint4 nx[Q];
+#endif
 #pragma unroll
-      for (int part = 0; part < CF; ++part) {
-        if (more) load_rec(nx, colbase + 64 * CF + part * 64 + lane);
-        for (int r0 = part * (RB / CF); r0 < (part + 1) * (RB / CF) && r0 < nr; r0 += 4) {
-          u32 sg[4];
-          u32 any = 0;
+      for (int b = 0; b < CF; ++b) load_col_fold(da, cfn[b], nxt + b * 64 + lane);
+      u32 acc[CF];                                          // after np rows: bit np-1-r = row r is inside its bound
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint4 f0 = rfold[(r0 + u) * RFS];
-            u32 rf[8] = {f0.x, f0.y, f0.z, f0.w, 0, 0, 0, 0};
-            if constexpr (B > 4) {
-              const uint4 f1 = rfold[(r0 + u) * RFS + 1];
-              rf[4] = f1.x; rf[5] = f1.y; rf[6] = f1.z; rf[7] = f1.w;
-            }
-            const u32 nb = (u32)__builtin_amdgcn_readlane((int)nbv, r0 + u);
-            sg[u] = 0;
+      for (int b = 0; b < CF; ++b) acc[b] = 0;
+      u32 rf[GR][B], rn[GR][B];
 #pragma unroll
-            for (int b = 0; b < CF; ++b) {
-              u32 t = rf[0] ^ cf[b][0];
+      for (int u = 0; u < GR; ++u) load_row_fold(da, rf[u], u);
+      const int np = (nr + GR - 1) / GR * GR;
+      for (int r0 = 0; r0 < np; r0 += GR) {
 #pragma unroll
-              for (int pl = 1; pl < B; ++pl) t = __builtin_amdgcn_bitop3_b32(rf[pl], cf[b][pl], t, PG_BITOP_XOR_OR);
-              sg[u] |= (u32)__builtin_popcount(t) + nb;     // lb - bound: negative = may be within the bound
-            }
-            any |= sg[u];
+        for (int u = 0; u < GR; ++u) load_row_fold(da, rn[u], r0 + GR + u);
+        u32 t[GR][CF];
+#pragma unroll
+        for (int u = 0; u < GR; ++u)
+#pragma unroll
+          for (int b = 0; b < CF; ++b) {
+            t[u][b] = rf[u][0] ^ cf[b][0];
+#pragma unroll
+            for (int pl = 1; pl < B; ++pl) t[u][b] = __builtin_amdgcn_bitop3_b32(rf[u][pl], cf[b][pl], t[u][b], PG_BITOP_XOR_OR);
           }
-          if (__builtin_amdgcn_ballot_w64((int)any < 0)) {  // rare once the bounds are tight
 #pragma unroll
-            for (int u = 0; u < 4; ++u) pend |= __builtin_amdgcn_ballot_w64((int)sg[u] < 0) ? 1u << (r0 + u) : 0u;
+        for (int u = 0; u < GR; ++u) {
+          const u32 nb = (u32)__builtin_amdgcn_readlane((int)nbv, r0 + u);
+#pragma unroll
+          for (int b = 0; b < CF; ++b)                      // lb - bound: negative = may be within the bound
+            acc[b] = __builtin_amdgcn_alignbit(acc[b], (u32)__builtin_popcount(t[u][b]) + nb, 31);
+        }
+#pragma unroll
+        for (int u = 0; u < GR; ++u)
+#pragma unroll
+          for (int pl = 0; pl < B; ++pl) rf[u][pl] = rn[u][pl];
+      }
+      int ncand = 0;
+      if constexpr (MODE == PG_MODE_KNN) {
+        // the hits, lane-parallel: per slice every lane that holds any queues its lowest one, until none is left
+        // (one or two turns as a rule; the order of a row's candidates does not matter to its list)
+#pragma unroll
+        for (int b = 0; b < CF; ++b) {
+          u32 a = acc[b];
+          u64 mb = __builtin_amdgcn_ballot_w64(a != 0);
+          while (mb) {
+            const u32 j = (u32)__builtin_ctz(a | 0x80000000u);
+            if (a != 0) cq[qn + mask_rank(mb)] = ((u32)(np - 1) - j) << SH | ((u32)colbase + b * 64 + lane);
+            const int n = (int)__popcll(mb);
+            qn += n;
+            ncand += n;
+            a &= a - 1;
+            if (qn >= 64) flush();                          // (at most 63 + 64 entries before it)
+            mb = __builtin_amdgcn_ballot_w64(a != 0);
           }
         }
-        if (more) fold_rec(nx, cfn[part]);
-      }
-      // the row-steps that passed: records back from L2, exact distances, epilogue (one code site; a row's
-      // columns stay in ascending order)
-      const int passed = __builtin_popcount(pend);
-      PG_ST(5, passed);
-      while (pend) {
-        const int rr = __builtin_ctz(pend);
-        pend &= pend - 1;
-        const u32 bnd = 0u - (u32)__builtin_amdgcn_readlane((int)nbv, rr);
-        for (int h = 0; h < CF / C; ++h) {
-          uint4 c[C][Q];
+      } else {
+        // the hits, row by row (a row's columns stay in ascending order in the queue: slices, then lanes)
+        u32 all = acc[0];
 #pragma unroll
-          for (int b = 0; b < C; ++b) load_rec(c[b], colbase + (h * C + b) * 64 + lane);
-          row_exact(c, rr, (u32)colbase + h * C * 64 + lane, kEps ? p.span + 1u : bnd);
+        for (int b = 1; b < CF; ++b) all |= acc[b];
+        u32 rowsHit = (u32)__builtin_amdgcn_readlane((int)wave_or_to63(all), 63);
+        while (rowsHit) {
+          const int j = __builtin_ctz(rowsHit);
+          rowsHit &= rowsHit - 1;
+          const u32 erow = (u32)(np - 1 - j) << SH;
+#pragma unroll
+          for (int b = 0; b < CF; ++b) {
+            const bool hit = (acc[b] >> j) & 1u;
+            const u64 mb = __builtin_amdgcn_ballot_w64(hit);
+            if (mb) {
+              if (hit) cq[qn + mask_rank(mb)] = erow | ((u32)colbase + b * 64 + lane);
+              const int n = (int)__popcll(mb);
+              qn += n;
+              ncand += n;
+              if (qn >= 64) flush();                        // (at most 63 + 64 entries before it)
+            }
+          }
         }
       }
-      return passed;
+      PG_ST(5, ncand);
+      PG_T1(14, tt0);
+      return ncand;
     };
 
     // kNN checkpoints (first super-tile after them): after 1/32 of the sweep a row without any near
@@ -603,29 +675,25 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         }
       }
     };
-    const bool canFold = p.filter != 0 && (kEps || thrLane < 56);   // PG_LB_FILTER=0: the exact form throughout
+    const bool canFold = canFilter;                         // PG_LB_FILTER=0 (or too many columns for queue entries): exact form only
     bool prefilter = canFold;
     int exact_left = 0;
     auto run_dense = [&](int S0, int S1) -> int {           // super-tiles [S0, S1); returns where it stopped (>= S1)
-      while (qn > 0) flush();                               // in-place results must come after queued ones
-      if (canFold) fold_rows();
       constexpr int F = PG_MM_ST / (64 * C);                // exact tiles per super-tile
       int s = S0;
       while (s < S1) {
         if (prefilter && !(s & 1)) {
           // folded tiles of two super-tiles each while the bound stays selective
           u32 cf[CF][B], cfn[CF][B];
-          {
-            uint4 nx[Q];
 #pragma unroll
-            for (int b = 0; b < CF; ++b) { load_rec(nx, (long long)s * PG_MM_ST + b * 64 + lane); fold_rec(nx, cf[b]); }
-          }
+          for (int b = 0; b < CF; ++b) load_col_fold(dense_args(), cf[b], (long long)s * PG_MM_ST + b * 64 + lane);
           while (s < S1) {
-            const bool more = s + 2 < S1;
-            const int passed = tile_folded(cf, cfn, (long long)s * PG_MM_ST, more);
+            const long long colbase = (long long)s * PG_MM_ST;
+            const int ncand = tile_folded(cf, cfn, colbase, s + 2 < S1 ? colbase + 64 * CF : colbase);
             s += 2;
             checkpoint(s - 2, s);
-            if (passed * 2 > nr) { prefilter = false; exact_left = 16; break; }
+            // a candidate costs about three instructions of a gather batch, an exact row-step 25 per 64 columns
+            if (ncand > 16 * nr) { prefilter = false; exact_left = 16; break; }
 #pragma unroll
             for (int b = 0; b < CF; ++b)
 #pragma unroll
@@ -633,6 +701,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           }
         } else {
           // exact form: to the end of the run, or until the bound is due for another probe
+          while (qn > 0) flush();                           // in-place results must come after queued ones
           int s1 = S1;
           if (prefilter) s1 = s + 1;                        // an odd super-tile in front of the folded tiles
           else if (canFold && s + exact_left < S1) s1 = s + exact_left;
@@ -660,33 +729,29 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     };
 
     int send = nst;
-    int drun = p.mmDirectRun;                               // super-tiles per dense run
+    int drun = 0;                                           // super-tiles per dense run (0: the first of a series)
     const int sbeg = kSym ? (int)(pr0 / PG_MM_ST) : 0;     // EPS_SYM: from the super-tile that holds the pass's first row
     for (;;) {
       int S = sbeg;
+      if (!canFilter) S = run_dense(S, send);               // no filter: the exact form throughout
       while (S < send) {
-        bool direct = !canFilter;
-        int S1 = send;
-        if (canFilter) {
-          if (!sweep_mfma(S, S + 1 < send ? S + 1 : S)) {   // the common case: the MFMA form did the super-tile
-            checkpoint(S, S + 1);
-            ++S;
-            drun = p.mmDirectRun;
-            continue;
-          }
-          // the signature is not selective here: a run of the dense form
-          S1 = S + drun < send ? S + drun : send;
-          direct = true;
-          drun = drun * 2 < 8 * p.mmDirectRun ? drun * 2 : 8 * p.mmDirectRun;   // back off while every probe is dense
-          ringS = -1;                                       // the fragments prefetched before the run are stale:
+        if (!sweep_mfma(S, S + 1 < send ? S + 1 : S)) {     // the common case: the MFMA form did the super-tile
+          checkpoint(S, S + 1);
+          ++S;
+          drun = 0;
+          continue;
+        }
+        // the signature is not selective here: a run of the dense form
+        const int drun0 = K().mmDirectRun;
+        if (!drun) drun = drun0;
+        const int S1 = S + drun < send ? S + drun : send;
+        drun = drun * 2 < 8 * drun0 ? drun * 2 : 8 * drun0;  // back off while every probe is dense
+        ringS = -1;                                         // the fragments prefetched before the run are stale:
 #pragma unroll
-          for (int i = 0; i < 4; ++i) ring[i] = pg_v4i{0, 0, 0, 0};   // dead across the run (frees their registers there)
-        }
-        if (direct) {
-          PG_ST(3, 1);
-          PG_ST(4, S1 - S);
-          S = run_dense(S, S1);                             // checkpoints inside; a folded tile may end one past S1
-        }
+        for (int i = 0; i < 4; ++i) ring[i] = pg_v4i{0, 0, 0, 0};   // dead across the run (frees their registers there)
+        PG_ST(3, 1);
+        PG_ST(4, S1 - S);
+        S = run_dense(S, S1);                               // checkpoints inside; a folded tile may end one past S1
       }
       while (qn > 0) flush();
       if constexpr (MODE == PG_MODE_KNN) {
@@ -705,25 +770,34 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     if constexpr (kEps) {
       if (lane < nr) p.counts[pr0 + lane] = cntv;
     } else {
+      const auto &kr = K();
       for (int rr = 0; rr < nr; ++rr) {
         const u32 key = lstbuf[wv][rr][lane];
-        if (lane >= p.knnFirst && lane < p.knnFirst + p.k) {
-          const long long o = (pr0 + rr) * (long long)p.k + (lane - p.knnFirst);
-          p.knnIdx[o] = (key == 0xFFFFFFFFu) ? -1 : (int)(key & 0x00FFFFFFu);
-          p.knnDist[o] = (unsigned char)(key >> 24);
+        if (lane >= kr.knnFirst && lane < kr.knnFirst + kr.k) {
+          const long long o = (pr0 + rr) * (long long)kr.k + (lane - kr.knnFirst);
+          kr.knnIdx[o] = (key == 0xFFFFFFFFu) ? -1 : (int)(key & 0x00FFFFFFu);
+          kr.knnDist[o] = (unsigned char)(key >> 24);
         }
-        if (p.lastKeys && lane == thrLane) p.lastKeys[pr0 + rr] = key;
+        if (kr.lastKeys && lane == thrLane) kr.lastKeys[pr0 + rr] = key;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    PG_T1(15, tp0);
+#ifdef PG_MM_STATS
+    if (p.stats && lane == 0 && gw < 65536) {                // (one pass a wave unless PG_ROWS_PER_WAVE > 32)
+      p.stats[16 + 2 * gw] = tr0;                    // 100 MHz wall clock at the start of the pass
+      p.stats[16 + 2 * gw + 1] = (__builtin_amdgcn_s_memrealtime() - tr0) | ((unsigned long long)(st[5] - st5_0) << 24) |
+                                         ((unsigned long long)(st[2] - st2_0) << 44) | ((unsigned long long)(st[7] - st7_0) << 54);
+    }
+#endif
   }
 #ifdef PG_MM_STATS
   {
     u32 v = 0;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) v = lane == i ? st[i] : v;
-    if (p.stats && lane < 12) atomicAdd(&p.stats[lane], (unsigned long long)v);
+    for (int i = 0; i < 16; ++i) v = lane == i ? st[i] : v;
+    if (p.stats && lane < 16) atomicAdd(&p.stats[lane], (unsigned long long)v);
   }
 #endif
 }

@@ -10,10 +10,11 @@ import numpy as np, torch
 from prograph_amd import _native as nat, synth
 
 NAMES = ["L1 super-tiles", "with candidates", "dense tiles, every distance", "dense runs", "dense super-tiles", "dense row-steps past the bound",
-         "candidates queued", "flushes", "insertions/matches", "resweep super-tiles", "passes", "dense tiles, folded bound"]
+         "candidates queued", "flushes", "insertions/matches", "resweep super-tiles", "passes", "dense tiles, folded bound",
+         "x64 cycles in flush", "x64 cycles in kNN insertion loops", "x64 cycles in folded tiles (incl. their flushes)", "x64 cycles in passes"]
 lib = nat.lib()
 def stats(reset=True):
-    buf = (ctypes.c_ulonglong * 12)()
+    buf = (ctypes.c_ulonglong * 16)()
     lib.pg_debug_stats(buf, 1 if reset else 0)
     return list(buf)
 def timed(f):

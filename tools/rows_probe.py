@@ -1,4 +1,5 @@
-"""Rows per wave of the MFMA engine against the tail of the grid (kNN 16, N=200k): PG_ROWS_PER_WAVE sweep."""
+"""How the kNN sweep of the MFMA engine scales with the number of row passes (tail of the grid):
+kNN 16 of the first `nrows` rows against all N=200k columns."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,7 +13,7 @@ def t(f, iters=5):
     return float(np.median(ts))
 for name, tok in (("cfg3", synth.clustered_tokens(200000, 64)), ("dense", synth.clustered_tokens(200000, 64, members=200000))):
     p = nat.pack(torch.from_numpy(tok), bits=5)
-    out = (torch.empty((200000, 16), dtype=torch.int32, device=p.buf.device), torch.empty((200000, 16), dtype=torch.uint8, device=p.buf.device))
-    for rpw in (32, 30, 28, 25, 24, 20, 16, 64):
-        os.environ["PG_ROWS_PER_WAVE"] = str(rpw)
-        print(f"{name:6s} rows/wave {rpw:3d}  {t(lambda: nat.knn_graph(p, p, 16, out=out)):8.3f} ms", flush=True)
+    for nrows in (32768, 65536, 98304, 131072, 163840, 200000):
+        out = (torch.empty((nrows, 16), dtype=torch.int32, device=p.buf.device), torch.empty((nrows, 16), dtype=torch.uint8, device=p.buf.device))
+        ms = t(lambda: nat.knn_graph(p, p, 16, row0=0, nrows=nrows, out=out))
+        print(f"{name:6s} rows {nrows:7d} = {nrows / 32 / 1024:5.2f} waves/SIMD  {ms:8.3f} ms   {ms / nrows * 32768:7.3f} ms per 32k rows", flush=True)
