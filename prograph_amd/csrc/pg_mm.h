@@ -318,15 +318,17 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           const int row = (int)__builtin_amdgcn_readlane(erow, j);
           const u32 x = __builtin_amdgcn_readlane(key, j);
           if (p.floorKeys && x <= __builtin_amdgcn_readlane(floorv, row)) continue;   // continuation round
+          const u32 othr = (u32)__builtin_amdgcn_readlane((int)thrv, row);
+          if (x >= othr) continue;                          // the row's threshold moved on meanwhile (no LDS trip)
           u32 lst = lstbuf[wv][row][lane];
-          if (x < __builtin_amdgcn_readlane(lst, thrLane) && !(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
+          if (!(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
             const u32 prev = wave_shr1(lst, 0u);
             lst = (lst <= x) ? lst : (prev > x ? prev : x);
             lstbuf[wv][row][lane] = lst;
             PG_ST(8, 1);
             const u32 nthr = __builtin_amdgcn_readlane(lst, thrLane);
             thrv = (lane == row) ? nthr : thrv;
-            publish(row, nthr);
+            if ((nthr >> 24) != (othr >> 24)) publish(row, nthr);   // the filter's bound only knows the distance
           }
         }
         PG_T1(13, ti0);
