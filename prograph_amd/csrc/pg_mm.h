@@ -606,6 +606,12 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           for (int pl = 0; pl < B; ++pl) rf[u][pl] = rn[u][pl];
       }
       int ncand = 0;
+      u32 all = acc[0];
+#pragma unroll
+      for (int b = 1; b < CF; ++b) all |= acc[b];
+      // three lanes of four with a hit: the bound is not selective here (bounds still loose, eps graphs of dense
+      // data, unrelated sequences).  Nothing is queued - the caller takes the tile again in the exact form
+      if (__popcll(__builtin_amdgcn_ballot_w64(all != 0)) >= 48) return -1;
       if constexpr (MODE == PG_MODE_KNN) {
         // the hits, lane-parallel: per slice every lane that holds any queues its lowest one, until none is left
         // (one or two turns as a rule; the order of a row's candidates does not matter to its list)
@@ -626,9 +632,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         }
       } else {
         // the hits, row by row (a row's columns stay in ascending order in the queue: slices, then lanes)
-        u32 all = acc[0];
-#pragma unroll
-        for (int b = 1; b < CF; ++b) all |= acc[b];
         u32 rowsHit = (u32)__builtin_amdgcn_readlane((int)wave_or_to63(all), 63);
         while (rowsHit) {
           const int j = __builtin_ctz(rowsHit);
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     };
     const bool canFold = canFilter;                         // PG_LB_FILTER=0 (or too many columns for queue entries): exact form only
     bool prefilter = canFold;
-    int exact_left = 0;
+    int exact_left = 0, exact_run = 16;
     auto run_dense = [&](int S0, int S1) -> int {           // super-tiles [S0, S1); returns where it stopped (>= S1)
       constexpr int F = PG_MM_ST / (64 * C);                // exact tiles per super-tile
       int s = S0;
@@ -692,8 +695,15 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           while (s < S1) {
             const long long colbase = (long long)s * PG_MM_ST;
             const int ncand = tile_folded(cf, cfn, colbase, s + 2 < S1 ? colbase + 64 * CF : colbase);
+            if (ncand < 0) {                                // not selective at all: this tile again, in the exact form,
+              prefilter = false;                            // and twice as long until the next probe (16 .. 256 super-tiles)
+              exact_left = exact_run;
+              exact_run = exact_run < 256 ? exact_run * 2 : 256;
+              break;
+            }
             s += 2;
             checkpoint(s - 2, s);
+            exact_run = 16;
             // a candidate costs about three instructions of a gather batch, an exact row-step 25 per 64 columns
             if (ncand > 16 * nr) { prefilter = false; exact_left = 16; break; }
 #pragma unroll
