@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
   if (s >= npad) return;
   const T *row = nullptr;
   if (s < n) row = src + (rows ? rows[s] : s) * ld;
-  u32 bad = 0, fold[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u32 bad = 0, fold[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sigw[2] = {0, 0};
   for (int g = 0; g < ng; ++g) {
     u32 pl[B];
 #pragma unroll
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
     }
 #pragma unroll
     for (int p = 0; p < B; ++p) fold[p] ^= pl[p];         // plane folds: XOR of each plane's group words
+    sigw[g & 1] ^= pl[0];                                 // plane 0, even / odd groups: the 64 bits behind the signature
 #pragma unroll
     for (int p = 0; p < B; ++p) {
       const int w = p * ng + g;               // plane-major record order
@@ -110,17 +111,16 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
     }
   }
   for (int w = ng * B; w < nq * 4; ++w) planes[((long long)(w >> 2) * npad + s) * 4 + (w & 3)] = 0;
-  // Signature section (after the nq chunk arrays, 32 * npad bytes): the column operands of the filter
-  // MFMAs (pg_mm.h) for the 31-bit signature of plane 0's fold, one byte per signature bit, per 32
-  // sequences one 1 KiB block in fragment order: uint4 [tile][h * 32 + c] = bytes k = 16h .. 16h+15
-  // of sequence 32 * tile + c; byte 31 is the constant 1 that multiplies the row's bias (0 for
-  // padding sequences: they never pass).
+  // Signature section (after the nq chunk arrays, 32 * npad bytes): the column operands of the filter MFMAs
+  // (pg_mm.h), v_mfma_f32_32x32x64_f8f6f4 with FP4 elements: 1.0 (0x2) per set bit of the 54-bit signature,
+  // 1.0 in the ten bias slots k = 54..63 (0 for padding sequences: they never pass); per 32 sequences one
+  // 1 KiB block in fragment order: uint4 [tile][h * 32 + c] = elements k = 32h .. 32h+31 of sequence 32 * tile + c.
   {
-    const u32 s31 = pg_sig31(fold[0]);
+    const unsigned long long sig = pg_sig54(sigw[0], sigw[1]);
+    const u32 lo = (u32)sig, hi = (u32)(sig >> 32) | (row ? 0xFFC00000u : 0u);
     uint4 *e = reinterpret_cast<uint4 *>(planes + (long long)nq * npad * 4) + (s >> 5) * 64 + (s & 31);
-    e[0] = make_uint4(pg_spread4(s31), pg_spread4(s31 >> 4), pg_spread4(s31 >> 8), pg_spread4(s31 >> 12));
-    e[32] = make_uint4(pg_spread4(s31 >> 16), pg_spread4(s31 >> 20), pg_spread4(s31 >> 24),
-                       pg_spread4(s31 >> 28) | (row ? 0x01000000u : 0u));
+    e[0] = make_uint4(pg_nib8(lo) << 1, pg_nib8(lo >> 8) << 1, pg_nib8(lo >> 16) << 1, pg_nib8(lo >> 24) << 1);
+    e[32] = make_uint4(pg_nib8(hi) << 1, pg_nib8(hi >> 8) << 1, pg_nib8(hi >> 16) << 1, pg_nib8(hi >> 24) << 1);
   }
   // Fold section (after the signatures, 32 * npad bytes): two uint4 arrays, planes 0..3 and 4..7 of every
   // sequence's plane folds (unused planes 0): the operands of the dense form's folded-exact bound.
@@ -691,10 +691,11 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   if (k < 1 || first < 0 || first > 1 || first + k > 64) return fail(PG_E_BADARG, "pg_knn_hamming: k out of range");
   if (ncols > PG_MAX_N_KNN) return fail(PG_E_TOOMANY, "pg_knn_hamming: ncols exceeds 2^24");
   p.k = k; p.knnFirst = first; p.floorKeys = floor_keys; p.lastKeys = last_keys;
-  // optimistic stage-1 cap (pg_nsq.h): 8 = half of what unrelated sequences show in the plane-0 bound
-  // (pg_mm.h: 7 - a tile of 1024 pairs is examined as soon as one pair passes, so false candidates cost more there;
-  //  6 is 3 % faster on 256-member clusters but 30 % slower on 64-member ones: profiles/r02_engine_landscape.txt)
-  p.knnGuess = getenv("PG_KNN_GUESS") ? (u32)atoi(getenv("PG_KNN_GUESS")) : (use_mm_engine(nrows) ? 7u : 8u);
+  // optimistic stage-1 cap.  pg_nsq.h: 8 = half of what unrelated sequences show in its 32-bit plane-0 bound.
+  // pg_mm.h: 10 with the 54-bit signature (L > 32) - unrelated pairs below it are one in 3e6, kNN time is flat from
+  // 7 to 12 on every shape tried (tools/guess_sweep.py) and rows whose k-th distance reaches 9 keep their cap;
+  // 7 where the signature is the 32 plane-0 bits of a single group (L <= 32: one in 4e3 at 7, one in 400 at 10)
+  p.knnGuess = getenv("PG_KNN_GUESS") ? (u32)atoi(getenv("PG_KNN_GUESS")) : (use_mm_engine(nrows) ? (l > 32 ? 10u : 7u) : 8u);
   if (p.filter == 0) p.knnGuess = 0;                       // no stage 1, nothing to cap
   p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;

@@ -147,6 +147,18 @@ struct HammingMetric {
     for (int g = 1; g < G; ++g) s ^= w[g];
     return s;
   }
+  // plane-0 words folded to two: XOR over the even groups, XOR over the odd groups (the 64 bits the MFMA
+  // engine's signature is cut from: pg_sig54)
+  static __device__ __forceinline__ void fold2(const uint4 (&rec)[Q], u32 &even, u32 &odd) {
+    u32 w[4 * Q];
+    unpack<Q>(rec, w);
+    even = w[0];
+    odd = G > 1 ? w[1] : 0u;
+#pragma unroll
+    for (int g = 2; g < G; ++g) {
+      if (g & 1) odd ^= w[g]; else even ^= w[g];
+    }
+  }
   // XOR fold of plane `pl`'s words over all groups (the signature of that plane; pl = 0: fold())
   static __device__ __forceinline__ u32 fold_plane(const uint4 (&rec)[Q], int pl) {
     u32 w[4 * Q];
@@ -220,6 +232,40 @@ __device__ __forceinline__ u32 wave_or_to63(u32 v) {
 }
 __device__ __forceinline__ u32 wave_shr1(u32 v, u32 fill) {
   return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+// ---- filter signature of the MFMA engine (pg_mm.h; written by pg_pack_planes) -------------------------------
+// v_mfma_f32_32x32x64_f8f6f4 with FP4 (E2M1) operands: K = 64 four-bit elements in the 16 bytes a lane holds,
+// at the cycles of the int8 32x32x32 form.  54 of them carry the signature - the plane-0 bits of the sequence,
+// 64 positions folded to 54 by XOR (a differing signature bit = an odd number of the positions folded onto it
+// differ in bit 0, so popcount(sig_a ^ sig_b) <= Hamming distance) - and 10 carry the row's bias.
+#define PG_SIG_BITS 54
+#define PG_SIG_BIAS 10       // bias elements: sums of +-{1, 2, 3, 4, 6} reach every integer in [-60, 58] but -59
+__host__ __device__ __forceinline__ unsigned long long pg_sig54(u32 even, u32 odd) {
+  const unsigned long long s = (unsigned long long)even | ((unsigned long long)odd << 32);
+  return (s & ((1ull << PG_SIG_BITS) - 1ull)) ^ (s >> PG_SIG_BITS);
+}
+// 8 bits -> 8 nibbles, bit i in bit 0 of nibble i
+__host__ __device__ __forceinline__ u32 pg_nib8(u32 x) {
+  u32 t = x & 0xFFu;
+  t = (t | (t << 12)) & 0x000F000Fu;
+  t = (t | (t << 6)) & 0x03030303u;
+  t = (t | (t << 3)) & 0x11111111u;
+  return t;
+}
+// ten FP4 nibbles (40 bits, element k = 54 + i in nibble i) whose sum is the largest representable value
+// <= b, b clamped to [-60, 58]: q sixes, then the remainder (5 = 4 + 1); exact except b = -59 (-> -60) and 59
+__host__ __device__ __forceinline__ unsigned long long pg_bias_nibbles(int b) {
+  const bool neg = b < 0;
+  u32 v = (u32)(neg ? -b : b);
+  if (neg) v = v > 60u ? 60u : (v == 59u ? 60u : v);
+  else v = v > 58u ? 58u : v;
+  const u32 q = (v * 43u) >> 8, r = v - 6u * q;            // v <= 60
+  unsigned long long s = q ? (0x7777777777ull >> (4u * (10u - q))) : 0ull;
+  s |= ((0x260605040200ull >> (8u * r)) & 0xFFull) << (4u * q);
+  const u32 cnt = q + (r == 0u ? 0u : (r == 5u ? 2u : 1u));
+  if (neg && cnt) s |= 0x8888888888ull >> (4u * (10u - cnt));
+  return s;
 }
 
 // Parameters of the all-pairs engine (one struct so the per-Q translation units share it)

@@ -6,36 +6,39 @@
 // ascending order, so eps matches come out in `torch.where` order and kNN lists need no merge);
 // what changed is how the ~97 % of pairs that cannot match are rejected.
 //
-// Stage 1 as an int8 MFMA.  The 31-bit filter signature of a sequence (XOR fold of its plane-0
-// words, pg_common.h) gives   lb(i,j) = popcount(s_i ^ s_j) <= d(i,j).   That popcount is bilinear:
+// Stage 1 as an MFMA.  The filter signature of a sequence (its plane-0 bits, 64 positions XOR-folded to
+// 54: pg_sig54 in pg_common.h) gives   lb(i,j) = popcount(s_i ^ s_j) <= d(i,j).   That popcount is bilinear:
 //     lb = pa_i - sum_k a'_ik * b_jk        a' = +1 / -1 per signature bit of the row,
 //                                           b  =  1 /  0 per signature bit of the column,
-// so with  A_ik = -a'_ik  (k < 31),  A_i,31 = pa_i - bound_i,  B_kj = b_jk,  B_31,j = 1
+// so with  A_ik = -a'_ik  (k < 54),  sum_{k >= 54} A_ik = pa_i - bound_i,  B_kj = b_jk,  B_kj = 1 (k >= 54)
 //     D = A x B = lb(i,j) - bound_i,        "may be below the row's bound"  <=>  D < 0.
-// One v_mfma_i32_32x32x32_i8 evaluates 32 rows x 32 columns; the 16 result registers are OR-ed
-// (8 v_or3) and ONE sign test + scalar branch decides whether the tile holds any candidate:
-// ~0.17 VALU instructions per 64 pairs instead of ~2.9 (pg_nsq.h), with the 1024 multiply-adds on
-// a pipe the VALU does not compete for.  Measured on MI355X (tools/ubench/mfma_s1.hip, N = 200k
-// full sweep): 1.45 ms against 3.6 ms for the xor + bcnt form; insensitive to occupancy (2..8
-// waves per SIMD) and to how many row blocks share a column fragment, i.e. not bound by the
-// 1 KiB-per-MFMA fragment stream from L2.
-//   * the row operand A (4 VGPRs) is built once per pass and stays in registers; a row's bound is
-//     ONE byte of it (lane 32+row, top byte of A[3]) and is rewritten in place when the row's
-//     threshold moves (kNN) - no LDS traffic for bounds at all;
-//   * the column operand comes from the signature section of the plane buffer ("E", written by
-//     pg_pack_planes): per 32 columns one 1 KiB block in MFMA fragment order, so a B operand is a
-//     single coalesced global_load_dwordx4; a ring of four tiles is in flight;
-//   * candidates (D < 0) are queued as (row, column) in LDS and evaluated exactly 64 at a time, one
-//     per lane, with gathered records - as in pg_nsq.h, but now for every candidate (the column
-//     records are no longer in registers);
-//   * DENSE data (mutant libraries: most pairs pass the plane-0 bound) climbs a hierarchy per
-//     super-tile of 128 columns.  Level 1 = the plane-0 signature above.  When more than 3/4 of a
-//     super-tile's (column, 16-row) lane slots hold a level-1 candidate, level 2 evaluates the
-//     signatures of bit planes 0..3 (one MFMA each, sign bits AND-ed: a pair can only be within the
-//     bound if it is within it in every plane; that leaves little more than the true matches).  When level 2 is dense too (the true matches themselves are dense: loose eps, or
-//     kNN rows whose lists are still open) the wave runs the DIRECT form for 8 super-tiles: whole
-//     column records in registers, every exact distance computed in place (the form pg_nsq.h
-//     falls back to as well), then probes again.
+// The instruction is v_mfma_f32_32x32x64_f8f6f4 with FP4 (E2M1) operands: K = 64 elements in the SAME 16
+// bytes per lane and the SAME cycles as the int8 32x32x32 form the first version used (31 bits + bias byte;
+// tools/ubench/mfma_fp4.hip checks operand layout and exactness: +-1, 0 and the bias values +-{1,2,3,4,6}
+// are FP4 numbers, sums of 64 of them are exact in f32, D = 0 comes out as +0).  54 bits instead of 31 cost
+// nothing and make unrelated pairs invisible up to bounds of ~12 (one in 3e6 at 10; the 31-bit form let one
+// in 2e3 pass at 7): cfg3 3.73 -> 3.55 ms, a 125k x 1M slice 9.3 -> 6.1 ms, and the optimistic kNN cap could
+// go from 7 to 10.
+// One MFMA evaluates 32 rows x 32 columns; the 16 result registers are OR-ed (8 v_or3) and ONE sign test +
+// scalar branch per four of them decides whether the super-tile holds any candidate: ~0.56 VALU instructions
+// per 64 pairs instead of ~2.9 (pg_nsq.h), with the multiply-adds on a pipe the VALU does not compete for.
+// Measured on MI355X for the int8 form (tools/ubench/mfma_s1.hip, N = 200k full sweep): 1.45 ms against
+// 3.6 ms for xor + bcnt; insensitive to occupancy (2..8 waves per SIMD) and to how many row blocks share a
+// column fragment, i.e. not bound by the 1 KiB-per-MFMA fragment stream from L2.
+//   * the row operand A (4 VGPRs) is built once per pass and stays in registers; a row's bias is ten nibbles
+//     of it (lane 32+row: top byte of A[2] and A[3]; pg_bias_nibbles).  When a row's distance threshold moves
+//     (kNN) the operand is only marked stale and re-encoded for all rows before the next super-tile: a stale
+//     bias is looser, never wrong;
+//   * the column operand comes from the signature section of the plane buffer (written by pg_pack_planes):
+//     per 32 columns one 1 KiB block in MFMA fragment order, so a B operand is a single coalesced
+//     global_load_dwordx4; a ring of four tiles is in flight;
+//   * candidates (D < 0) are queued as (row, column) in LDS and evaluated exactly 64 at a time, one per lane,
+//     with gathered records - as in pg_nsq.h, but now for every candidate (the column records are no longer
+//     in registers);
+//   * DENSE data (mutant libraries, one big cluster: most pairs pass the plane-0 bound) leaves the MFMA form
+//     per run of super-tiles for the folded form (plane folds of all bit planes, B + 1 instructions per 64
+//     pairs, hits into the same candidate queue) or, where even that is not selective, the exact form (every
+//     distance in place, pg_nsq.h's direct form); see "dense forms" below.
 // kNN keeps the optimistic cap / checkpoint / second-phase scheme of pg_nsq.h (exactness argument
 // there and in DESIGN.md §4.1); only the representation of the bound changed.
 #pragma once
@@ -57,15 +60,17 @@ static_assert(PG_MM_QCAP >= 63 + 64, "a register push adds up to 64 candidates t
 static_assert(PG_QCAP >= 63 + 4 * 2 * PG_PUSH_MAX, "pg_nsq.h kNN queue: a group pushes up to 4 rows x 2 columns x PG_PUSH_MAX");
 static_assert(PG_QCAP_EPS >= 63 + 4 * 2 * 64, "pg_nsq.h eps queue: a group pushes up to 4 rows x 2 x 64 lanes");
 
-// 31-bit filter signature from the 32-bit XOR fold (bit 31 folds onto bit 0: still "an odd number
-// of the positions folded onto this bit differ", i.e. still a lower bound)
-__device__ __forceinline__ u32 pg_sig31(u32 s) { return (s ^ (s >> 31)) & 0x7FFFFFFFu; }
+typedef int pg_v8i __attribute__((ext_vector_type(8)));
+typedef float pg_v16f __attribute__((ext_vector_type(16)));
 
-// 4 signature bits -> 4 bytes with bit i in the LSB of byte i
-__device__ __forceinline__ u32 pg_spread4(u32 nib) { return ((nib & 0xFu) * 0x00204081u) & 0x01010101u; }
-
-// row operand bytes: bit set -> -1 (0xFF), bit clear -> +1 (0x01)
-__device__ __forceinline__ u32 pg_expand_pm1(u32 nib) { return 0x01010101u + pg_spread4(nib) * 0xFEu; }
+// D = A x B over K = 64 FP4 elements (only the first four registers of each operand are read); the result
+// comes back as its bit patterns: the filter looks at signs only, and sums of these small integers are exact
+__device__ __forceinline__ pg_v16i pg_mfma_fp4(const pg_v4i &a, const pg_v4i &b) {
+  const pg_v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+  const pg_v16f zero = {0};
+  const pg_v16f d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, zero, 4, 4, 0, 0, 0, 0);
+  return __builtin_bit_cast(pg_v16i, d);
+}
 
 __device__ __forceinline__ int pg_or16(const pg_v16i &d) {
   int a = d[0] | d[1] | d[2];
@@ -174,40 +179,45 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- row operand of the MFMA: lane l holds row l & 31, signature bits 16*(l >> 5) .. +15 ----
+    // ---- row operand of the MFMA: lane l holds row l & 31, elements k = 32*(l >> 5) .. +31 as FP4 nibbles:
+    // signature bit set -> -1.0 (0xA), clear -> +1.0 (0x2); k = 54..63 (top byte of A0[2] and A0[3] of lanes
+    // 32..) = the bias pa - bound as a sum of up to ten elements, so D = lb - bound and its sign is the answer ----
     u32 pa0;
     pg_v4i A0;
     {
       uint4 rec[Q];
 #pragma unroll
       for (int q = 0; q < Q; ++q) rec[q] = rowbuf[wv][lane & 31][q];
-      const u32 s31 = pg_sig31(M::fold(rec));
-      pa0 = (u32)__builtin_popcount(s31);
-      const u32 half = (s31 >> (16 * (lane >> 5))) & 0xFFFFu;
-      A0[0] = (int)pg_expand_pm1(half);
-      A0[1] = (int)pg_expand_pm1(half >> 4);
-      A0[2] = (int)pg_expand_pm1(half >> 8);
-      A0[3] = (int)pg_expand_pm1(half >> 12);
+      u32 even, odd;
+      M::fold2(rec, even, odd);
+      const unsigned long long sig = pg_sig54(even, odd);
+      pa0 = (u32)__builtin_popcountll(sig);
+      const u32 half = lane >> 5 ? (u32)(sig >> 32) : (u32)sig;
+      A0[0] = (int)(0x22222222u | (pg_nib8(half) << 3));
+      A0[1] = (int)(0x22222222u | (pg_nib8(half >> 8) << 3));
+      A0[2] = (int)(0x22222222u | (pg_nib8(half >> 16) << 3));
+      A0[3] = (int)(0x22222222u | (pg_nib8(half >> 24) << 3));
     }
-    // A row's bound: lanes 32.. hold it in boundv (authoritative) and, as pa - bound clamped to int8,
-    // in the top byte of A0[3] (k = 31).  A bound beyond pa + 128 passes everything either way.
+    // A row's bound: lanes 32.. hold it in boundv (authoritative) and as bias nibbles in their operand.
+    // A bound beyond pa + 60 passes everything either way (lb <= 54).  A bound that moves (kNN: always down)
+    // only marks the operand stale; the next super-tile of the MFMA form re-encodes all rows at once - one
+    // copy of the encoder, one pass per flush instead of one per insertion; a stale bias is merely looser.
     u32 boundv = 0;
-    auto bias_byte = [&](u32 pa, u32 bound) -> u32 {
-      int b = (int)pa - (int)bound;
-      b = b < -128 ? -128 : b;
-      return ((u32)b & 0xFFu) << 24;
+    bool stale = false;
+    auto refresh_bias = [&]() {
+      const unsigned long long nb = pg_bias_nibbles(boundv > 255u ? -60 : (int)pa0 - (int)boundv);
+      const bool up = lane >= 32;
+      A0[2] = up ? (int)(((u32)A0[2] & 0x00FFFFFFu) | ((u32)nb << 24)) : A0[2];
+      A0[3] = up ? (int)(u32)(nb >> 8) : A0[3];
+      stale = false;
     };
     auto set_bound = [&](int row, u32 bound) {              // row, bound wave uniform
-      const u32 nb = ((u32)A0[3] & 0x00FFFFFFu) | bias_byte(pa0, bound);
-      const bool me = lane == 32 + row;
-      A0[3] = me ? (int)nb : A0[3];
-      boundv = me ? bound : boundv;
+      boundv = (lane == 32 + row) ? bound : boundv;
+      stale = true;
     };
     auto set_all_bounds = [&](u32 bv) {                     // bv: lane r < 32 holds row r's bound
-      const u32 g = (u32)__builtin_amdgcn_ds_bpermute((lane & 31) << 2, (int)bv);
-      const u32 nb = ((u32)A0[3] & 0x00FFFFFFu) | bias_byte(pa0, g);
-      A0[3] = (lane >= 32) ? (int)nb : A0[3];
-      boundv = g;
+      boundv = (u32)__builtin_amdgcn_ds_bpermute((lane & 31) << 2, (int)bv);
+      stale = true;                                         // (may loosen bounds: every caller is followed by sweep_mfma's refresh)
     };
 
     // Per-row state, lane indexed (lane = row in pass), touched with v_readlane / lane selects:
@@ -380,7 +390,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // sign test + branch; a consumed fragment register is refilled at once with the next super-tile's
     // (four loads in flight).  A tile that holds candidates is evaluated AGAIN in the slow path
     // (fragment re-read from L2): one copy of the queueing code, no result registers live across it. ----
-    const pg_v16i zero16 = {0};
     // queue the candidates (negative entries) of one tile's result registers
     // C/D layout of the 32x32 MFMA: register r, lane l -> row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31
     auto queue_from = [&](const pg_v16i &d, int tile) {
@@ -428,22 +437,23 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     int ringS = -1;                                         // super-tile whose fragments the ring holds
     // one super-tile in the MFMA form; returns true when the signature is not selective here (nothing was queued)
     auto sweep_mfma = [&](int S, int Snext) -> bool {
+      if (stale) refresh_bias();
       if (ringS != S) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) ring[i] = colsig[(long long)(S * 4 + i) * 64 + lane];
       }
       const pg_v4i *nx = colsig + (long long)Snext * 4 * 64 + lane;
-      pg_v16i d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[0], zero16, 0, 0, 0);
+      pg_v16i d0 = pg_mfma_fp4(A0, ring[0]);
       ring[0] = nx[0];
-      pg_v16i d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[1], zero16, 0, 0, 0);
+      pg_v16i d1 = pg_mfma_fp4(A0, ring[1]);
       ring[1] = nx[64];
       const int a0 = pg_or16(d0);
       __builtin_amdgcn_sched_barrier(0);                    // two result sets in turn, not four (the 128-VGPR budget)
-      d0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[2], zero16, 0, 0, 0);
+      d0 = pg_mfma_fp4(A0, ring[2]);
       ring[2] = nx[128];
       const int a1 = pg_or16(d1);
       __builtin_amdgcn_sched_barrier(0);
-      d1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, ring[3], zero16, 0, 0, 0);
+      d1 = pg_mfma_fp4(A0, ring[3]);
       ring[3] = nx[192];
       const int a2 = pg_or16(d0);
       const int a3 = pg_or16(d1);
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         const int i = __builtin_ctz(tm);
         tm &= tm - 1;
         const int tile = S * 4 + i;
-        const pg_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, colsig[(long long)tile * 64 + lane], zero16, 0, 0, 0);
+        const pg_v16i d = pg_mfma_fp4(A0, colsig[(long long)tile * 64 + lane]);
         queue_from(d, tile);
       }
       return false;
