@@ -51,7 +51,7 @@ VALU_PEAK = CUS * SIMDS * CLOCK_HZ / 2.0          # 1.2288e12 wave-instructions/
 # measured mixed-stream ceiling of this kernel's instruction classes (v_bcnt / v_cmp / v_or3 at ~4.2 cycles,
 # logic ops at ~2.3, profiles/r01_valu_issue_microbench.txt): reported beside the guide's peak
 VALU_MIX_CEILING = CUS * SIMDS * CLOCK_HZ / 4.2
-MFMA_I8_CYCLES = 32.0                              # v_mfma_i32_32x32x32_i8: cycles per instruction per SIMD
+MFMA_I8_CYCLES = 32.0                              # v_mfma_f32_32x32x64_f8f6f4 (FP4) = the int8 32x32x32 form: cycles per instruction per SIMD
 
 WORKLOADS = {
     "cfg2": dict(N=50_000, L=32, mode="eps", eps=2, k=None, shards=1),
@@ -329,7 +329,7 @@ def roofline(rec, wl, pmc, sha):
                  "PMC pass (null when the kernel sources changed since); kernel_ms is this run's HIP-event time"}
     if mfma:
         r["mfma"] = {"instr_per_launch": mfma, "pipe_busy_frac": mfma * MFMA_I8_CYCLES / (CUS * SIMDS * CLOCK_HZ * rec["kern_ms"] * 1e-3),
-                     "note": "v_mfma_i32_32x32x32_i8 (stage-1 signature filter), 32 cycles per instruction per SIMD at 2.4 GHz"}
+                     "note": "v_mfma_f32_32x32x64_f8f6f4 with FP4 operands (stage-1 signature filter, K = 54 signature bits + 10 bias slots), 32 cycles per instruction per SIMD at 2.4 GHz"}
     if wl["mode"] == "lev":
         r["kernel"] = "pg_lev_* (profile + bag filter pg_nsq_kernel<BagMetric> + pg_lev_select_kernel)"
         r["note"] = "kernel_ms spans the Levenshtein launches (filter + exact distances + selection); VALU-issue bound; " + r["note"]

@@ -27,8 +27,9 @@
  * lane as a single fully coalesced 1 KiB `global_load_dwordx4`, and the Hamming distance of
  * two records is B+1 VALU instructions per 32 tokens (xor, v_bitop3 x (B-1), v_bcnt).
  * Behind the Q chunk arrays the buffer carries the SIGNATURE SECTION (32 * Npad bytes): per sequence
- * the 31-bit filter signature (XOR fold of its plane-0 dwords) expanded to one byte per bit, per 32
- * sequences one 1 KiB block in int8-MFMA fragment order - the column operand of the matrix-core
+ * the 54-bit filter signature (its plane-0 bits, 64 positions XOR-folded to 54) as FP4 (E2M1) elements -
+ * 1.0 per set bit, then ten 1.0 bias slots (0 for padding sequences) - per 32 sequences one 1 KiB block in
+ * v_mfma_f32_32x32x64_f8f6f4 fragment order: the column operand of the matrix-core
  * filter stage of the all-pairs engine (prograph_amd/csrc/pg_mm.h) - and behind it the FOLD SECTION
  * (32 * Npad bytes): two 16-byte arrays of Npad entries with the sequence's plane folds (plane p's G
  * dwords XOR-ed into one), planes 0..3 and 4..7 (unused planes zero) - the operands of the engine's
