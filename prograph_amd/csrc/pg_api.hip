@@ -10,6 +10,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 
 static thread_local char g_err[256] = "";
 
@@ -550,7 +552,31 @@ static void plan_mm(int64_t nrows, NsqParams *p, int *grid) {
   if (!g_stats) pg_debug_stats(nullptr, 1);
   p->stats = g_stats;
 #endif
-  *grid = (int)((waves + PG_WG_WAVES - 1) / PG_WG_WAVES);
+  // persistent waves: at most one per slot of the chip (whole workgroups), the rest of the passes through the counter
+  long long gridWaves = waves < slots ? waves : slots;
+  if (const char *pe = getenv("PG_MM_PERSISTENT")) { if (atoi(pe) == 0) gridWaves = waves; }
+  gridWaves = (gridWaves + PG_WG_WAVES - 1) / PG_WG_WAVES * PG_WG_WAVES;
+  p->mmPasses = waves; p->mmGridWaves = gridWaves;
+  *grid = (int)(gridWaves / PG_WG_WAVES);
+}
+// The pass counter of a launch: one of a ring of 256 device words, zeroed on the launch's stream right before
+// the kernel (concurrent launches on different streams get different words).
+static int pass_counter(NsqParams *p, hipStream_t s) {
+  static unsigned *ring = nullptr;
+  static std::atomic<unsigned> next{0};
+  if (!ring) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (!ring) {
+      unsigned *r = nullptr;
+      if (hipMalloc(&r, 256 * 64) != hipSuccess) return fail(PG_E_NODEV, "pass counters: hipMalloc failed");
+      ring = r;
+    }
+  }
+  unsigned *c = ring + 16 * (next.fetch_add(1) & 255u);    // one counter per 64-byte line
+  if (hipMemsetAsync(c, 0, 4, s) != hipSuccess) return fail(PG_E_NODEV, "pass counters: hipMemsetAsync failed");
+  p->mmPassCounter = c;
+  return 0;
 }
 
 int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
@@ -566,6 +592,7 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
   int grid = 0;
   if (use_mm_engine(nrows)) {
     plan_mm(nrows, &p, &grid);
+    if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
     return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps)");
   }
   if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS, bits), 16.0 * pg_nchunks(l, bits))) return rc;
@@ -594,6 +621,7 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
   // N = 100k .. 200k (more rows: too few waves to balance; fewer: the per-wave column stream shows).
   if (use_mm_engine(n)) {
     plan_mm(n, &p, &grid);
+    if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
     return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS_SYM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps sym)");
   }
   if (!getenv("PG_ROWS_PER_WAVE") && !getenv("PG_WAVES_PER_CU")) {
@@ -679,6 +707,7 @@ int pg_eps_fill_rows(const void *row_planes, int64_t row_npad, int64_t row0, con
   p.slotIdx = indices; p.slotW = weights; p.counts = scratch_counts;
   int grid = 0;
   plan_mm(n_list, &p, &grid);
+  if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
   return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps fill)");
 }
 
@@ -701,6 +730,7 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   int grid = 0;
   if (use_mm_engine(nrows)) {
     plan_mm(nrows, &p, &grid);
+    if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
     return launched(kMm[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn)");
   }
   if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits), 16.0 * pg_nchunks(l, bits), PG_RB_KNN)) return rc;

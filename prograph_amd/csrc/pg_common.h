@@ -283,6 +283,8 @@ struct NsqParams {
   int rowsPerWave, rowsPerPass;
   long long mmTailFrom;   // pg_mm.h: waves from this index on take mmTailRows rows each (the last, partly filled round of the grid)
   int mmTailRows;
+  long long mmPasses, mmGridWaves;   // pg_mm.h: passes in all; waves in the grid (wave w starts with pass w, then takes
+  unsigned *mmPassCounter;           // mmGridWaves + atomicAdd(counter) until none is left); the counter starts at 0
   int mmDenseL1, mmDenseL2, mmDirectRun;   // pg_mm.h: density rules of the filter hierarchy
   int filter;   // 1 = plane-0 lower-bound filter allowed (adaptive per tile), 0 = always direct
   u32 knnGuess; // kNN: optimistic cap on the stage-1 bound until a row's list is full (0 = off), see pg_nsq.h

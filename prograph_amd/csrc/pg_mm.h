@@ -99,12 +99,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
-  // the rows of this wave: rowsPerWave each, smaller shares (mmTailRows) in the last round of the grid
-  const bool tailWave = gw >= p.mmTailFrom;
-  const long long wrows = tailWave ? p.mmTailRows : p.rowsPerWave;
-  const long long wr0 = tailWave ? p.mmTailFrom * p.rowsPerWave + (gw - p.mmTailFrom) * p.mmTailRows : gw * p.rowsPerWave;
-  if (wr0 >= p.nrows) return;   // whole wave leaves; no workgroup barrier is used below
-  const long long wr1 = (wr0 + wrows < p.nrows) ? wr0 + wrows : p.nrows;
+  if (gw >= p.mmPasses) return;   // whole wave leaves; no workgroup barrier is used below
   const uint4 *__restrict__ colp = p.colPlanes;
   const pg_v4i *__restrict__ colsig = reinterpret_cast<const pg_v4i *>(p.colSig);
   const u32 ncols = (u32)p.ncols;
@@ -137,8 +132,16 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
 #define PG_T0(v)
 #define PG_T1(i, v)
 #endif
-  for (long long pr0 = wr0; pr0 < wr1; pr0 += RB) {
-    const long long left = wr1 - pr0;
+  // Passes are handed out dynamically: the grid holds one wave per slot of the chip (pg_api.hip: plan_mm),
+  // wave gw starts with pass gw and fetches further ones from a counter.  The hardware dispatcher refills the
+  // CUs whose workgroups end first to full occupancy and leaves the others idle for the last round of a longer
+  // grid; persistent waves spread that round over all SIMDs, where its waves run faster (fewer per SIMD).
+  for (long long pass = gw; pass < p.mmPasses;) {
+    // the rows of the pass: rowsPerWave each, mmTailRows from pass mmTailFrom on
+    const bool tailPass = pass >= p.mmTailFrom;
+    const long long prows = tailPass ? p.mmTailRows : p.rowsPerWave;
+    const long long pr0 = tailPass ? p.mmTailFrom * p.rowsPerWave + (pass - p.mmTailFrom) * p.mmTailRows : pass * p.rowsPerWave;
+    const long long left = (pr0 + prows < p.nrows ? pr0 + prows : p.nrows) - pr0;
     PG_ST(10, 1);
     PG_T0(tp0);
 #ifdef PG_MM_STATS
@@ -807,12 +810,16 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     __builtin_amdgcn_wave_barrier();
     PG_T1(15, tp0);
 #ifdef PG_MM_STATS
-    if (p.stats && lane == 0 && gw < 65536) {                // (one pass a wave unless PG_ROWS_PER_WAVE > 32)
-      p.stats[16 + 2 * gw] = tr0;                    // 100 MHz wall clock at the start of the pass
-      p.stats[16 + 2 * gw + 1] = (__builtin_amdgcn_s_memrealtime() - tr0) | ((unsigned long long)(st[5] - st5_0) << 24) |
+    if (p.stats && lane == 0 && pass < 65536) {
+      p.stats[16 + 2 * pass] = tr0;                    // 100 MHz wall clock at the start of the pass
+      p.stats[16 + 2 * pass + 1] = (__builtin_amdgcn_s_memrealtime() - tr0) | ((unsigned long long)(st[5] - st5_0) << 24) |
                                          ((unsigned long long)(st[2] - st2_0) << 44) | ((unsigned long long)(st[7] - st7_0) << 54);
     }
 #endif
+    // the next pass of this wave
+    u32 nx = 0;
+    if (lane == 0) nx = atomicAdd(p.mmPassCounter, 1u);
+    pass = p.mmGridWaves + (long long)(u32)__builtin_amdgcn_readfirstlane((int)nx);
   }
 #ifdef PG_MM_STATS
   {
