@@ -108,7 +108,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   u32 *cq = &cqbuf[wv][0];
   const u32 bias = kEps ? opaque_vgpr(0u - p.lo) : 0u;     // eps: -lo rides in the popcount accumulator
   // eps entries carry the row in 5 bits above a 27-bit column; wider problems run the direct form
-  const bool canFilter = p.filter != 0 && (!kEps || p.ncols < (1ll << 27));
+  const bool canFilterK = p.filter != 0 && (!kEps || p.ncols < (1ll << 27));   // (per pass: canFilter below)
   constexpr int SH = kEps ? 27 : 24;
   // arguments that only cold code needs (staging a pass, storing results, the dense forms) are read from the
   // kernel-argument segment where they are used: held in SGPRs across the sweep they crowd the loop state of
@@ -160,12 +160,23 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     }
     // eps: where row `lane` of the pass stores its matches: its slot, or (fill pass) its place in the CSR
     u32 baselo = 0, basehi = 0;
+    bool passDense = false;
     if constexpr (kEps) {
       long long b = 0;
       if (lane < nr) b = ka.fillIndptr ? ka.fillIndptr[ka.rowList ? ka.rowList[pr0 + lane] : pr0 + lane] : (pr0 + lane) * (long long)ka.cap;
       baselo = (u32)b;
       basehi = (u32)((unsigned long long)b >> 32);
+      // fill pass: the rows' degrees are known (their CSR extents).  A pass whose rows match one column in 32 or
+      // more on average is swept in the exact form from the start: no filter can beat "every distance" there
+      if (ka.fillIndptr) {
+        long long deg = 0;
+        if (lane < nr) deg = ka.fillIndptr[(ka.rowList ? ka.rowList[pr0 + lane] : pr0 + lane) + 1] - b;
+        u32 dsum = (u32)(deg > 0x3FFFFFF ? 0x3FFFFFF : deg);  // (32 rows x 2^26 fits 32 bits)
+        for (int o = 32; o > 0; o >>= 1) dsum += (u32)__shfl_xor((int)dsum, o);
+        passDense = (unsigned long long)dsum * 32ull >= (unsigned long long)nr * (unsigned long long)p.ncols;
+      }
     }
+    const bool canFilter = canFilterK && !passDense;
     auto row_base = [&](int row) -> long long {
       // (readlane returns a signed int: without the u32 casts a low half with bit 31 set sign-extends into the high half)
       const u32 lo32 = (u32)__builtin_amdgcn_readlane((int)baselo, row), hi32 = (u32)__builtin_amdgcn_readlane((int)basehi, row);
@@ -565,6 +576,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       PG_ST(2, 1);
       const u32 col0 = (u32)(dt * (64 * C)) + lane;
       const u32 nbv = neg_bounds();                         // a row's bound only matters before its own step
+      // (round 1's two-rows-in-turn pipelining of the LDS reads costs more here than it saves: two more record
+      // sets push the kernel into spills - dense eps 30.9 -> 34.1 ms, random kNN 22.6 -> 23.7)
       for (int rr = 0; rr < nr; ++rr) {
         const u32 bnd = 0u - (u32)__builtin_amdgcn_readlane((int)nbv, rr);
         if (bnd) row_exact(c, rr, col0, kEps ? p.span + 1u : bnd);
@@ -580,11 +593,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       PG_ST(11, 1);
       PG_T0(tt0);
       const DenseArgs da = dense_args();
-#if defined(PG_DBG) && PG_DBG == 3
-      const u32 nbv = neg_bounds() & ((u32)p.filter >> 8);
-#else
       const u32 nbv = neg_bounds();
-#endif
 #pragma unroll
       for (int b = 0; b < CF; ++b) load_col_fold(da, cfn[b], nxt + b * 64 + lane);
       u32 acc[CF];                                          // after np rows: bit np-1-r = row r is inside its bound

@@ -76,3 +76,15 @@ def test_no_product_import_of_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "prograph_oracle" in src:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_signature_helpers_on_the_host():
+    """tests/capi/sig_check.cpp: the arithmetic behind the MFMA engine's FP4 signature filter
+    (prograph_amd/csrc/pg_common.h) compiled for the host - bit spreading, the ten-element encoding of a
+    row's bias for every value (never above the bias, exact except -59), XOR-linearity and the
+    lower-bound property of the 54-bit signature.  Runs on the CPU."""
+    import subprocess
+    capi = os.path.join(REPO, "tests", "capi")
+    subprocess.check_call(["make", "-s", "-C", capi, "_build/sig_check"])
+    out = subprocess.run([os.path.join(capi, "_build", "sig_check")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "signature helpers OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

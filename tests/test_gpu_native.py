@@ -788,3 +788,18 @@ def test_eps_graph_with_more_than_2_31_entries(nat, engine):
         cols = np.nonzero(d > 0)[0]
         a, b = int(ip[r]), int(ip[r + 1])
         assert np.array_equal(idx[a:b].cpu().numpy(), cols) and np.array_equal(w[a:b].cpu().numpy(), d[cols]), r
+
+
+@pytest.mark.gpu
+def test_mfma_fp4_operand_layout_and_exactness():
+    """tools/ubench/mfma_fp4.hip: v_mfma_f32_32x32x64_f8f6f4 with FP4 operands against a CPU product - the lane /
+    nibble layout the pack kernel and the engine's row operand assume, and exact sums of the values they use."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "..", "tools", "ubench", "mfma_fp4.hip")
+    exe = os.path.join(here, "capi", "_build", "mfma_fp4")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-Wno-unused-result", src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "layout confirmed" in out.stdout, out.stdout + out.stderr
