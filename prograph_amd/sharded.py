@@ -45,8 +45,26 @@ def _comm(world, rank, dev, group=None):
         box = [_native.comm_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
-        with torch.cuda.device(dev):
-            _COMMS[key] = _native.comm_init(world, rank, box[0])
+        comm, err = None, None
+        try:
+            with torch.cuda.device(dev):
+                comm = _native.comm_init(world, rank, box[0])
+        except Exception as e:          # noqa: BLE001 - reported below, never silent
+            err = e
+        if world > 1:
+            # every rank must take the same road: agree on "all communicators are up"
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    _native.comm_destroy(comm)
+                import sys
+                print(f"[prograph_amd] rank {rank}: pg_comm_init failed on at least one rank ({err!r}); "
+                      "the shards are gathered with torch.distributed's RCCL all-gather instead", file=sys.stderr, flush=True)
+                comm = False
+        elif comm is None:
+            raise err
+        _COMMS[key] = comm
     return _COMMS[key]
 
 
@@ -68,7 +86,13 @@ def allgather_tokens(local_tokens, n_total, group=None):
         padded[: local_tokens.shape[0]] = local_tokens
         local_tokens = padded
     if local_tokens.is_cuda and dist.get_backend(group) != "gloo":
-        return _native.allgather_tokens(_comm(world, rank, local_tokens.device, group), local_tokens, world)[:n_total]
+        comm = _comm(world, rank, local_tokens.device, group)
+        if comm is not False:
+            return _native.allgather_tokens(comm, local_tokens, world)[:n_total]
+        # the C-ABI communicator could not be created (reported on stderr): the same collective through torch's RCCL
+        full = torch.empty((per * world, L), dtype=local_tokens.dtype, device=local_tokens.device)
+        dist.all_gather_into_tensor(full, local_tokens.contiguous(), group=group)
+        return full[:n_total]
     full = torch.empty((per * world, L), dtype=local_tokens.dtype, device=local_tokens.device)
     if local_tokens.is_cuda:
         # rehearsal mode (several ranks sharing one GPU, CPU collectives): stage through the host
