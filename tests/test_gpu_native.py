@@ -803,3 +803,25 @@ def test_mfma_fp4_operand_layout_and_exactness():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-Wno-unused-result", src, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "layout confirmed" in out.stdout, out.stdout + out.stderr
+
+
+def test_concurrent_launches_on_two_streams(nat):
+    """The MFMA engine hands its passes out through a per-launch counter (persistent waves): launches that overlap
+    on different streams must not share one.  Two kNN sweeps of different row windows run concurrently, several
+    times over, and are compared with serial runs."""
+    from prograph_amd import synth
+    os.environ["PG_ENGINE"] = "mfma"
+    tok = synth.clustered_tokens(150000, 64, seed=5)
+    p = _planes(nat, tok, 5)
+    ref_a = nat.knn_graph(p, p, 8, row0=0, nrows=140000)
+    ref_b = nat.knn_graph(p, p, 8, row0=10000, nrows=140000)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(4):
+        with torch.cuda.stream(sa):
+            a = nat.knn_graph(p, p, 8, row0=0, nrows=140000)
+        with torch.cuda.stream(sb):
+            b = nat.knn_graph(p, p, 8, row0=10000, nrows=140000)
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], ref_a[0]) and torch.equal(a[1], ref_a[1])
+        assert torch.equal(b[0], ref_b[0]) and torch.equal(b[1], ref_b[1])
