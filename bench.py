@@ -281,7 +281,8 @@ def run_workload(name, G, rank, dev, use_dist, backend, steps, warmup, want_pcie
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in kern_ev]))
     ms_per_step = elapsed / steps * 1e3
     value = float(rows_local) * N * G * steps / elapsed         # every rank does rows_local x N
-    engine = "mfma" if rows_local >= int(os.environ.get("PG_ENGINE_MIN_ROWS", "40000")) else "valu"
+    thr_default = "60000" if (wl["mode"] == "eps" and L <= 32) else "40000"     # pg_api.hip: use_mm_engine
+    engine = "mfma" if rows_local >= int(os.environ.get("PG_ENGINE_MIN_ROWS", thr_default)) else "valu"
     engine = os.environ.get("PG_ENGINE", engine)
     rec = {"name": name, "N": N, "L": L, "k": k, "rows_local": rows_local, "kern_ms": kern_ms, "ms_per_step": ms_per_step,
            "value": value, "pcie_ms": pcie_ms, "result": result, "engine": engine}

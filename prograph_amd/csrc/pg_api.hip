@@ -491,12 +491,15 @@ static int fill_nsq(NsqParams *p, const void *row_planes, int64_t row_npad, int6
 // rows per wave) or pg_nsq.h (stage 1 on the VALU, 4..32 rows per wave).  PG_ENGINE=mfma / valu forces one.
 // Auto: the MFMA engine from 8 waves per SIMD-column on, i.e. once 32-row passes fill the chip; below
 // that the VALU engine's finer row split keeps more CUs busy.
-static bool use_mm_engine(int64_t nrows) {
+static bool use_mm_engine(int64_t nrows, int l = 64, bool knn = true) {
   if (const char *e = getenv("PG_ENGINE")) {
     if (!strcmp(e, "mfma")) return true;
     if (!strcmp(e, "valu")) return false;
   }
-  const long long thr = getenv("PG_ENGINE_MIN_ROWS") ? atoll(getenv("PG_ENGINE_MIN_ROWS")) : 40000;   // tools/engine_crossover.py: kNN crosses at ~32k rows, eps at ~40k
+  // tools/engine_crossover.py: kNN crosses at ~32k rows, eps at ~40k; eps graphs of sequences of one group
+  // (L <= 32: only 32 signature bits) at ~60k (N = 50k L = 32: VALU engine 0.70 ms, MFMA engine 0.75)
+  const long long dflt = (!knn && l <= 32) ? 60000 : 40000;
+  const long long thr = getenv("PG_ENGINE_MIN_ROWS") ? atoll(getenv("PG_ENGINE_MIN_ROWS")) : dflt;
   return nrows >= thr;
 }
 #ifdef PG_MM_STATS
@@ -590,7 +593,7 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
   p.hi1 = (p.lo > 0xFFFFFF00u - 1u) ? 0u : p.lo + p.span + 1u;   // empty interval: nothing can match
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
   int grid = 0;
-  if (use_mm_engine(nrows)) {
+  if (use_mm_engine(nrows, l, false)) {
     plan_mm(nrows, &p, &grid);
     if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
     return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps)");
@@ -619,7 +622,7 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
   // dispatched in row order, i.e. longest first, which balances by itself once there are a few
   // waves per resident slot.  Measured (tools/eps_sym_probe.py): 8 rows per wave at N = 50k, 16 at
   // N = 100k .. 200k (more rows: too few waves to balance; fewer: the per-wave column stream shows).
-  if (use_mm_engine(n)) {
+  if (use_mm_engine(n, l, false)) {
     plan_mm(n, &p, &grid);
     if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
     return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS_SYM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps sym)");
