@@ -528,7 +528,7 @@ static void plan_mm(int64_t nrows, NsqParams *p, int *grid) {
   const char *e = getenv("PG_ROWS_PER_WAVE");
   const char *t = getenv("PG_MM_TAIL");
   if (e && atoi(e) > 0) {
-    rpw = atoi(e);
+    rpw = atoi(e) < PG_MM_RB ? atoi(e) : PG_MM_RB;          // (a wave sweeps one pass of at most 32 rows at a time)
     tailFrom = (nrows + rpw - 1) / rpw; tailRows = rpw;
   } else {
     const long long full = nrows / (slots * PG_MM_RB) * slots;          // passes of the full rounds

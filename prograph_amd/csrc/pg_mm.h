@@ -52,8 +52,8 @@ typedef int pg_v16i __attribute__((ext_vector_type(16)));
 #define PG_MM_ST 128         // columns per super-tile: 4 MFMA tiles = one direct-form tile (C = 2)
 // defaults of the density rules (NsqParams carries them: PG_MM_L1 / PG_MM_RUN override for experiments)
 #define PG_MM_DENSE_L1 56    // of 256 lane slots per super-tile with a candidate: leave the MFMA form (tools/dense_knobs.py: 40..64 flat, 96 costs dense data 25 %)
-#define PG_MM_DENSE_L2 48    // (unused since the MFMA level 2 was dropped; kept in NsqParams for A/B builds)
-#define PG_MM_GROUP_ROWS 4    // folded form: rows per group (one sign test and one branch a group)
+#define PG_MM_DENSE_L2 48    // (unused since the MFMA level 2 was dropped; NsqParams still carries the field)
+#define PG_MM_GROUP_ROWS 4    // folded form: rows per group of straight-line code (their folds: 20 SGPRs in flight)
 #define PG_MM_DIRECT_RUN 8   // super-tiles of dense form before the MFMA filter is probed again
 
 static_assert(PG_MM_QCAP >= 63 + 64, "a register push adds up to 64 candidates to a queue holding up to 63");
@@ -495,14 +495,15 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     //  exact : the round-1 direct form - the records of 64*C columns per lane in registers (two sets, the
     //          next tile's loads in flight), every distance of every row-step, in-place epilogue
     //  folded: per lane the PLANE FOLDS of four columns (256 columns a tile, B words a column: the G group
-    //          words of a plane XOR-ed into one); popcount(OR_p(fold_p(row) ^ fold_p(col))) <= d - an exact
-    //          test of "differs nowhere" per folded position, B + 1 ops a column whatever L is.  Rows go four
-    //          to a group of straight-line code (row folds from LDS as broadcast reads, the negated bound
-    //          seeds the popcount: one sign test and ONE branch a group); a row-step that passes reloads the
-    //          column records from L2 and takes the exact path.  The next tile's records are loaded one
-    //          64-column slice at a time between the groups and folded as they arrive.
-    // A run starts in the folded form and falls back to `exact` while more than half of the row-steps pass
-    // (bounds still loose, or eps graphs of data this dense), probing again every 16 super-tiles.
+    //          words of a plane XOR-ed into one, from the fold section of the plane buffer);
+    //          popcount(OR_p(fold_p(row) ^ fold_p(col))) <= d - an exact test of "differs nowhere" per folded
+    //          position, B + 1 ops a column whatever L is.  Rows go four to a group of straight-line code, their
+    //          folds as SGPR operands (scalar loads), the negated bound seeds the popcount and the sign is shifted
+    //          into a per-slice hit mask: no branch in the row loop.  After the rows the hits join the candidate
+    //          queue of the MFMA form (exact distance from gathered records, 64 a batch).
+    // A run starts in the folded form and falls back to `exact` where the bound is not selective (hits in three
+    // lanes of four, or more than 16 candidates a row: bounds still loose, eps graphs of data this dense,
+    // unrelated sequences), probing again after 16 .. 256 super-tiles.
     constexpr int G = M::kGroups, B = M::kBits;
     constexpr int CF = 4;                                   // folded form: columns per lane
     // plane folds of sequences come from the fold section of the plane buffer (pg_pack_planes): the columns'
