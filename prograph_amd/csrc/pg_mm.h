@@ -457,36 +457,56 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         for (int i = 0; i < 4; ++i) ring[i] = colsig[(long long)(S * 4 + i) * 64 + lane];
       }
       const pg_v4i *nx = colsig + (long long)Snext * 4 * 64 + lane;
+      // kNN keeps the fragments in the ring until the sign test is through: a super-tile with candidates (one in
+      // five at cfg3) evaluates its flagged tiles again without a trip to L2 (cfg3 3.50 -> 3.35 ms).  The eps
+      // instances, where such super-tiles are rarer, refill each register right after its MFMA - the earlier
+      // loads are worth more there (cfg3 eps <= 2: 2.83 against 3.00 ms) - and re-read the fragment.
+      constexpr bool kKeep = MODE == PG_MODE_KNN;
       pg_v16i d0 = pg_mfma_fp4(A0, ring[0]);
-      ring[0] = nx[0];
+      if constexpr (!kKeep) ring[0] = nx[0];
       pg_v16i d1 = pg_mfma_fp4(A0, ring[1]);
-      ring[1] = nx[64];
+      if constexpr (!kKeep) ring[1] = nx[64];
       const int a0 = pg_or16(d0);
       __builtin_amdgcn_sched_barrier(0);                    // two result sets in turn, not four (the 128-VGPR budget)
       d0 = pg_mfma_fp4(A0, ring[2]);
-      ring[2] = nx[128];
+      if constexpr (!kKeep) ring[2] = nx[128];
       const int a1 = pg_or16(d1);
       __builtin_amdgcn_sched_barrier(0);
       d1 = pg_mfma_fp4(A0, ring[3]);
-      ring[3] = nx[192];
+      if constexpr (!kKeep) ring[3] = nx[192];
       const int a2 = pg_or16(d0);
       const int a3 = pg_or16(d1);
       ringS = Snext;
       PG_ST(0, 1);
       PG_ST(9, resweep);
-      if (!__builtin_amdgcn_ballot_w64((a0 | a1 | a2 | a3) < 0)) return false;
+      if (!__builtin_amdgcn_ballot_w64((a0 | a1 | a2 | a3) < 0)) {
+        if constexpr (kKeep) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ring[i] = nx[64 * i]; // the next super-tile's fragments (four loads in flight)
+        }
+        return false;
+      }
       PG_ST(1, 1);
       const u64 m0 = __builtin_amdgcn_ballot_w64(a0 < 0), m1 = __builtin_amdgcn_ballot_w64(a1 < 0);
       const u64 m2 = __builtin_amdgcn_ballot_w64(a2 < 0), m3 = __builtin_amdgcn_ballot_w64(a3 < 0);
-      u32 tm = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
       const int nslots = (int)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
-      if (nslots >= p.mmDenseL1) return true;               // most lane slots hold a candidate: the dense form takes over
-      while (tm) {                                          // ascending tiles: queue order = column order per row
-        const int i = __builtin_ctz(tm);
-        tm &= tm - 1;
-        const int tile = S * 4 + i;
-        const pg_v16i d = pg_mfma_fp4(A0, colsig[(long long)tile * 64 + lane]);
-        queue_from(d, tile);
+      if (nslots >= p.mmDenseL1) return true;               // most lane slots hold a candidate: the dense form takes over (ring dropped there)
+      if constexpr (kKeep) {
+        // (four copies of the queueing code: selecting the fragment by index instead cost 3x - the selects made
+        //  the compiler give up the ring's registers)
+        if (m0) { const pg_v16i d = pg_mfma_fp4(A0, ring[0]); ring[0] = nx[0]; queue_from(d, S * 4 + 0); } else ring[0] = nx[0];
+        if (m1) { const pg_v16i d = pg_mfma_fp4(A0, ring[1]); ring[1] = nx[64]; queue_from(d, S * 4 + 1); } else ring[1] = nx[64];
+        if (m2) { const pg_v16i d = pg_mfma_fp4(A0, ring[2]); ring[2] = nx[128]; queue_from(d, S * 4 + 2); } else ring[2] = nx[128];
+        if (m3) { const pg_v16i d = pg_mfma_fp4(A0, ring[3]); ring[3] = nx[192]; queue_from(d, S * 4 + 3); } else ring[3] = nx[192];
+      } else {
+        u32 tm = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
+        while (tm) {                                        // ascending tiles: queue order = column order per row
+          const int i = __builtin_ctz(tm);
+          tm &= tm - 1;
+          const int tile = S * 4 + i;
+          const pg_v16i d = pg_mfma_fp4(A0, colsig[(long long)tile * 64 + lane]);
+          queue_from(d, tile);
+        }
       }
       return false;
     };
