@@ -825,3 +825,26 @@ def test_concurrent_launches_on_two_streams(nat):
         torch.cuda.synchronize()
         assert torch.equal(a[0], ref_a[0]) and torch.equal(a[1], ref_a[1])
         assert torch.equal(b[0], ref_b[0]) and torch.equal(b[1], ref_b[1])
+
+
+def test_bench_json_line_contract():
+    """bench.py prints ONE JSON line with the driver's keys, a roofline object (bound / achieved / peak / unit /
+    frac / traffic) and a cpu_baseline slot; run on the smallest workload with two steps."""
+    import json, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PG_")}      # the bench's own engine choice
+    out = subprocess.run([sys.executable, os.path.join(here, "..", "bench.py"), "--workload", "cfg2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["higher_is_better"] is True
+    assert rec["value"] > 0 and rec["ms_per_step"] > 0 and "workload" in rec["config"] and rec["dtype"] == "u8"
+    roof = rec["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] in ("valu", "hbm", "mfma") and (roof["frac"] is None or 0 < roof["frac"] <= 1)
