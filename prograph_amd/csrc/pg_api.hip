@@ -504,10 +504,10 @@ static bool use_mm_engine(int64_t nrows, int l = 64, bool knn = true) {
 }
 #ifdef PG_MM_STATS
 static unsigned long long *g_stats = nullptr;
-extern "C" int pg_debug_stats(unsigned long long *out12, int reset) {   // debug builds only (tools/mm_stats.py); 16 counters
-  const size_t nst = 16 + 2 * 65536;                       // 16 counters, then (start, duration) of the first 65536 passes
+extern "C" int pg_debug_stats(unsigned long long *out12, int reset) {   // debug builds only (tools/mm_stats.py); PG_NSTAT counters
+  const size_t nst = PG_NSTAT + 2 * 65536;                 // the counters, then (start, duration) of the first 65536 passes
   if (!g_stats) { if (hipMalloc(&g_stats, nst * 8) != hipSuccess) return -1; hipMemset(g_stats, 0, nst * 8); }
-  if (out12) { hipDeviceSynchronize(); hipMemcpy(out12, g_stats, (reset & 2 ? nst : 16) * 8, hipMemcpyDeviceToHost); }
+  if (out12) { hipDeviceSynchronize(); hipMemcpy(out12, g_stats, (reset & 2 ? nst : PG_NSTAT) * 8, hipMemcpyDeviceToHost); }
   if (reset & 1) hipMemset(g_stats, 0, nst * 8);
   return 0;
 }
@@ -734,7 +734,12 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   if (use_mm_engine(nrows)) {
     plan_mm(nrows, &p, &grid);
     if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
-    return launched(kMm[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn)");
+    // short lists (the usual k): the instance that inserts a whole batch of candidates at once (pg_mm.h, KL).
+    // PG_MM_SHORT=0 keeps the 64-lane lists (A/B runs)
+    const bool shortList = first == 1 && k + 1 <= PG_MM_KL && !floor_keys && !last_keys &&
+                           !(getenv("PG_MM_SHORT") && atoi(getenv("PG_MM_SHORT")) == 0);
+    return launched(kMm[pg_ngroups(l) - 1](shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN, bits, p, grid, (hipStream_t)stream),
+                    "pg_mm_kernel(knn)");
   }
   if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits), 16.0 * pg_nchunks(l, bits), PG_RB_KNN)) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");

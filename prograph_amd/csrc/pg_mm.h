@@ -55,6 +55,7 @@ typedef int pg_v16i __attribute__((ext_vector_type(16)));
 #define PG_MM_DENSE_L2 48    // (unused since the MFMA level 2 was dropped; NsqParams still carries the field)
 #define PG_MM_GROUP_ROWS 4    // folded form: rows per group of straight-line code (their folds: 20 SGPRs in flight)
 #define PG_MM_DIRECT_RUN 8   // super-tiles of dense form before the MFMA filter is probed again
+#define PG_NSTAT 24          // debug builds (-DPG_MM_STATS): event / cycle counters per launch, then (start, duration) per pass
 
 static_assert(PG_MM_QCAP >= 63 + 64, "a register push adds up to 64 candidates to a queue holding up to 63");
 static_assert(PG_QCAP >= 63 + 4 * 2 * PG_PUSH_MAX, "pg_nsq.h kNN queue: a group pushes up to 4 rows x 2 columns x PG_PUSH_MAX");
@@ -72,31 +73,55 @@ __device__ __forceinline__ pg_v16i pg_mfma_fp4(const pg_v4i &a, const pg_v4i &b)
   return __builtin_bit_cast(pg_v16i, d);
 }
 
+// a | b | c as v_bitop3_b32 (truth table 0xFE): the 2-cycle issue class of xor / or / bitop3, where v_or3_b32 is in
+// the 4-cycle class (profiles/r01_valu_issue_microbench.txt: k_bitop3 2.4-2.9 cycles, k_or3 4.2-4.4)
+#ifndef PG_OR3_PLAIN
+__device__ __forceinline__ int pg_or3(int a, int b, int c) {
+  return (int)__builtin_amdgcn_bitop3_b32((u32)a, (u32)b, (u32)c, 0xFE);
+}
+#else
+__device__ __forceinline__ int pg_or3(int a, int b, int c) { return a | b | c; }
+#endif
+// median of three unsigned values (sorted insertion: new[i] = med3(old[i-1], key, old[i]))
+__device__ __forceinline__ u32 pg_med3(u32 a, u32 b, u32 c) {
+  u32 r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ int pg_or16(const pg_v16i &d) {
-  int a = d[0] | d[1] | d[2];
-  int b = d[3] | d[4] | d[5];
-  int c = d[6] | d[7] | d[8];
-  int e = d[9] | d[10] | d[11];
-  int f = d[12] | d[13] | d[14];
-  a = a | b | c;
-  e = e | f | d[15];
+  int a = pg_or3(d[0], d[1], d[2]);
+  int b = pg_or3(d[3], d[4], d[5]);
+  int c = pg_or3(d[6], d[7], d[8]);
+  int e = pg_or3(d[9], d[10], d[11]);
+  int f = pg_or3(d[12], d[13], d[14]);
+  a = pg_or3(a, b, c);
+  e = pg_or3(e, f, d[15]);
   return a | e;
 }
 
 // Records of up to three chunks (L <= 64 with 5 bit planes): held at 4 waves per SIMD (the kNN instance
 // would take 141 VGPRs; pinned to 128 it spills 7 of them outside the loops, measured faster)
-template <class M, int MODE>
+// KL (kNN only): entries of a row's list in LDS.  64 = the list lives across the wave's lanes (lane j = j-th smallest
+// key; insertion = one DPP shift, one candidate at a time).  KL < 64 (k + 1 <= KL, PG_MM_KL): the list is KL consecutive
+// dwords, RIGHT aligned (the (k+1)-th smallest key, i.e. the row's threshold, is always entry KL-1; unused entries in
+// front hold 0), and a flush inserts up to 64 candidates of different rows AT ONCE, one per lane: the winner lane of a row
+// reads its list (KL/4 ds_read_b128), new[i] = med3(old[i-1], key, old[i]), writes it back.
+template <class M, int MODE, int KL = 64>
 __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M::Q <= 3 ? 4 : 1, 8))) void pg_mm_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
+  constexpr bool kPar = MODE == PG_MODE_KNN && KL < 64;    // lane-per-candidate insertion
+  static_assert(KL == 64 || (KL % 4 == 0 && KL >= 8 && KL <= 32), "list entries: 64, or a multiple of 4 in 8..32");
   constexpr int C = Q <= 4 ? 2 : 1;                        // direct form: columns per lane
   constexpr bool kEps = MODE != PG_MODE_KNN;
   constexpr bool kSym = MODE == PG_MODE_EPS_SYM;
   constexpr int RB = PG_MM_RB;
   constexpr int LROWS = MODE == PG_MODE_KNN ? RB : 1;
   __shared__ uint4 rowbuf[PG_WG_WAVES][RB][Q];
-  __shared__ u32 lstbuf[PG_WG_WAVES][LROWS][64];           // kNN: per row, lane j = j-th smallest key
+  __shared__ __attribute__((aligned(16))) u32 lstbuf[PG_WG_WAVES][LROWS][KL];   // kNN: per row the sorted keys (see KL above)
   __shared__ u32 cqbuf[PG_WG_WAVES][PG_MM_QCAP];           // deferred candidates: row << SH | column
+  __shared__ u32 claimbuf[PG_WG_WAVES][kPar ? 32 : 1];     // kPar: per row the lane that inserts in this turn
   const int lane = threadIdx.x & 63;
+  const u32 ulane = (u32)lane;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
   if (gw >= p.mmPasses) return;   // whole wave leaves; no workgroup barrier is used below
@@ -121,9 +146,11 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   };
 
 #ifdef PG_MM_STATS
-  u32 st[16] = {0};   // 12..15: kilo-cycles (s_memtime) of this wave in flush / in its insertion loop / in folded tiles / in passes
-  u32 st_unused[1] = {0};   // 0 L1 super-tiles, 1 with candidates, 2 escalated to L2, 3 L2-dense (direct runs), 4 direct super-tiles,
-                      // 5 tiles queued from, 6 candidates queued, 7 flushes, 8 insertions / eps matches, 9 resweep super-tiles, 10 passes
+  u32 st[PG_NSTAT] = {0};   // 0 L1 super-tiles, 1 with candidates, 2 exact tiles, 3 dense runs, 4 dense super-tiles, 5 candidates of
+                      // folded tiles, 6 candidates queued, 7 flushes, 8 insertions / eps matches, 9 resweep super-tiles, 10 passes,
+                      // 11 folded tiles; x64 cycles (s_memtime) of this wave: 12 in flush, 13 in its insertion part, 14 in folded tiles,
+                      // 15 in passes, 16 in scan() (the hot loop), 17 in slow_mfma (queueing, its flushes included), 18 scan() calls,
+                      // 19 bias refreshes, 20 queueing turns, 21 x64 cycles from a pass's start to its first super-tile
 #define PG_ST(i, n) st[i] += (u32)(n)
 #define PG_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #define PG_T1(i, v) st[i] += (u32)((__builtin_amdgcn_s_memtime() - v) >> 6)
@@ -186,8 +213,16 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     u32 failed = 0;                                         // kNN: rows that lost their optimistic cap (bit = row, all 32 bits in use)
     u32 resweep = 0;                                        // kNN: 1 in phase 1 (early super-tiles again for the failed rows)
     int sredo = 0;                                          // kNN: super-tiles [0, sredo) are swept again for them
+    // list geometry: lanes / entries [lfirst, lfirst + k) are written out, entry thrLane is the row's threshold
+    const int thrLane = kPar ? KL - 1 : p.knnFirst + p.k - 1;   // last list entry that is still needed
+    const int lfirst = kPar ? KL - p.k : p.knnFirst;            // (kPar: the host guarantees knnFirst == 1, k + 1 <= KL)
+    const int lzero = kPar ? KL - 1 - p.k : 0;                   // kPar: entries below hold 0 (never displaced: keys are >= 0)
     if constexpr (MODE == PG_MODE_KNN) {
-      for (int rr = 0; rr < nr; ++rr) lstbuf[wv][rr][lane] = 0xFFFFFFFFu;
+      if constexpr (kPar) {
+        for (int e = lane; e < nr * KL; e += 64) (&lstbuf[wv][0][0])[e] = (e % KL) >= lzero ? 0xFFFFFFFFu : 0u;
+      } else {
+        for (int rr = 0; rr < nr; ++rr) lstbuf[wv][rr][lane] = 0xFFFFFFFFu;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -242,13 +277,19 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     if constexpr (MODE == PG_MODE_KNN) {
       if (ka.floorKeys && lane < nr) floorv = ka.floorKeys[pr0 + lane];
     }
-    const int thrLane = p.knnFirst + p.k - 1;               // last list lane that is still needed
     set_all_bounds(lane < nr ? (kEps ? p.hi1 : capv) : 0u); // rows past nr: bound 0, nothing passes
 
     auto publish = [&](int row, u32 thr) {                  // kNN: a row's threshold moved
       const u32 cp = __builtin_amdgcn_readlane(capv, row);
       const u32 b = (thr >> 24) + resweep;                  // phase 1: lb <= distance bound may still win a tie
       set_bound(row, b < cp ? b : cp);
+    };
+    // kNN: the bounds of ALL rows from the row-indexed state (after a flush that moved several thresholds at once):
+    // min(threshold distance [+1 in phase 1], cap); 0 for rows past nr and, in phase 1, for the frozen rows
+    auto republish_all = [&]() {
+      const bool live = lane < nr && (!resweep || ((failed >> (lane & 31)) & 1u));
+      const u32 b = (thrv >> 24) + resweep;                 // open lists read 255
+      set_all_bounds(live ? (b < capv ? b : capv) : 0u);
     };
     // EPS_SYM: a match (row, col), col > row, also belongs to row `col` (owned by another wave): its
     // entry goes to the BACK of that row's slot through an atomic counter (pg_compact_kernel sorts it)
@@ -293,18 +334,19 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         if (p.floorKeys) cand = cand && key > __builtin_amdgcn_readlane(floorv, rr);
         u64 m = __builtin_amdgcn_ballot_w64(cand);
         if (m) {
-          u32 lst = lstbuf[wv][rr][lane];
+          // (kPar: the list is entries 0..KL-1 = lanes 0..KL-1 here; the zeros in front of it stay where they are)
+          u32 lst = (!kPar || lane < KL) ? lstbuf[wv][rr][kPar ? (lane < KL ? lane : 0) : lane] : 0xFFFFFFFFu;
           do {
             const int j = __builtin_ctzll(m);
             m &= m - 1;
             const u32 x = __builtin_amdgcn_readlane(key, j);
-            if (x < thr && !(resweep && __builtin_amdgcn_ballot_w64(lst == x))) {
+            if (x < thr && !(resweep && __builtin_amdgcn_ballot_w64(lst == x && lane >= lzero))) {
               const u32 prev = wave_shr1(lst, 0u);
               lst = (lst <= x) ? lst : (prev > x ? prev : x);
               thr = __builtin_amdgcn_readlane(lst, thrLane);
             }
           } while (m);
-          lstbuf[wv][rr][lane] = lst;
+          if (!kPar || lane < KL) lstbuf[wv][rr][kPar ? (lane < KL ? lane : 0) : lane] = lst;
           thrv = (lane == rr) ? thr : thrv;
           publish(rr, thr);
         }
@@ -318,7 +360,72 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       PG_ST(7, 1);
       PG_T0(tf0);
       const u32 e = cq[lane];
-      if constexpr (MODE == PG_MODE_KNN) {
+      if constexpr (kPar) {
+        // every candidate of the batch at once: exact distance, then insertion by the candidate's own lane.  Two
+        // candidates of one row take turns (the row's claim word says whose turn it is; any order gives the same
+        // list: keys are totally ordered).
+        const u32 col = e & 0x00FFFFFFu;
+        const u32 erow = (e >> 24) & 31u;
+        const bool act = lane < nbat && col < ncols;
+        u32 key = 0xFFFFFFFFu;
+        if (act) {
+          uint4 cr[Q], rw[Q];                               // all gathers in flight at once
+#pragma unroll
+          for (int q = 0; q < Q; ++q) cr[q] = colp[(long long)q * p.colNpad + col];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) rw[q] = rowbuf[wv][erow][q];
+          key = (M::dist(rw, cr, 0u) << 24) | col;
+        }
+        const u32 thr0 = (u32)__builtin_amdgcn_ds_bpermute((int)(erow << 2), (int)thrv);
+        bool pend = act && key < thr0;
+        bool moved = false;                                 // the threshold DISTANCE of this lane's row changed
+        PG_T0(ti0);
+        while (__builtin_amdgcn_ballot_w64(pend)) {
+          // (LDS operations of a wave are processed in order: the last writer of a row's word wins.  The fences keep
+          // the compiler from forwarding a lane's own store to its load; a volatile pointer would lose the LDS address
+          // space: flat accesses and a full vmcnt wait per turn)
+          if (pend) claimbuf[wv][erow] = (u32)lane;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const bool win = pend && claimbuf[wv][erow] == (u32)lane;
+          u32 nthr = 0u;
+          if (win) {
+            uint4 *lp = reinterpret_cast<uint4 *>(&lstbuf[wv][erow][0]);
+            u32 o[KL];
+#pragma unroll
+            for (int i = 0; i < KL / 4; ++i) {
+              const uint4 v = lp[i];
+              o[4 * i] = v.x; o[4 * i + 1] = v.y; o[4 * i + 2] = v.z; o[4 * i + 3] = v.w;
+            }
+            const u32 othr = o[KL - 1];
+            bool ok = key < othr;                           // (the row's threshold may have moved on since thr0 was read)
+            if (resweep) {                                  // phase 1 meets columns again: no duplicates
+              bool dup = false;
+#pragma unroll
+              for (int i = 0; i < KL; ++i) dup = dup || (o[i] == key && i >= lzero);
+              ok = ok && !dup;
+            }
+            if (ok) {
+#pragma unroll
+              for (int i = KL - 1; i > 0; --i) o[i] = pg_med3(o[i - 1], key, o[i]);
+              o[0] = o[0] < key ? o[0] : key;
+#pragma unroll
+              for (int i = 0; i < KL / 4; ++i) lp[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+              nthr = o[KL - 1];
+              moved = moved || (nthr >> 24) != (othr >> 24);
+            }
+          }
+          PG_ST(8, __popcll(__builtin_amdgcn_ballot_w64(nthr != 0u)));
+          // the new thresholds back into the row-indexed vector (lane 63 is nobody's row; thresholds are never 0:
+          // entry KL-1 of a list sits behind at least one other key)
+          const u32 got = (u32)__builtin_amdgcn_ds_permute((int)((nthr ? erow : 63u) << 2), (int)nthr);
+          thrv = (lane < 32 && got != 0u) ? got : thrv;
+          pend = pend && !win;
+        }
+        if (__builtin_amdgcn_ballot_w64(moved)) republish_all();
+        PG_T1(13, ti0);
+      } else if constexpr (MODE == PG_MODE_KNN) {
         const u32 col = e & 0x00FFFFFFu;
         const u32 erow = (e >> 24) & 31u;
         const bool act = lane < nbat && col < ncols;
@@ -400,115 +507,145 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       PG_T1(12, tf0);
     };
 
-    // ---- filtered form.  Hot path per super-tile: four level-1 MFMAs, the OR of each result, ONE
-    // sign test + branch; a consumed fragment register is refilled at once with the next super-tile's
-    // (four loads in flight).  A tile that holds candidates is evaluated AGAIN in the slow path
-    // (fragment re-read from L2): one copy of the queueing code, no result registers live across it. ----
-    // queue the candidates (negative entries) of one tile's result registers
-    // C/D layout of the 32x32 MFMA: register r, lane l -> row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31
-    auto queue_from = [&](const pg_v16i &d, int tile) {
-      PG_ST(5, 0);
-      const u32 ebase = ((4u * (u32)(lane >> 5)) << SH) | (u32)(tile * 32 + (lane & 31));
-      int total = 0;
+    // ---- filtered form (the MFMA form) ----
+    // C/D layout of the 32x32 MFMA: register r, lane l -> row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31.
+    // The hot loop (scan) only looks at the OR of a tile's 16 result registers.  At a super-tile with candidates the
+    // flagged tiles are evaluated AGAIN from the ring and the SIGNS of the 16 registers are shifted into one word per
+    // lane (bit r = register r holds a candidate); the queueing code works from these four words - nothing else of
+    // the MFMA form is live across it.
+    auto signs16 = [&](const pg_v16i &d) -> u32 {
+      u32 a = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) total += (int)__popcll(__builtin_amdgcn_ballot_w64(d[r] < 0));
-      PG_ST(6, total);
-      u32 done = 0xFFFFu;                                   // result registers already queued
-      if (qn + total <= PG_MM_QCAP) {
-        // the usual case (a tile holds a dozen candidates): everything fits, straight-line pushes
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool hit = d[r] < 0;
-          const u64 mb = __builtin_amdgcn_ballot_w64(hit);
-          if (mb) {
-            if (hit) cq[qn + mask_rank(mb)] = ebase + ((u32)((r & 3) + 8 * (r >> 2)) << SH);
-            qn += (int)__popcll(mb);
+      for (int r = 15; r >= 0; --r) a = __builtin_amdgcn_alignbit(a, (u32)d[r], 31);   // (a << 1) | sign
+      return a;
+    };
+    // kNN (the order of a row's candidates does not matter to its list): LANE PARALLEL queueing - per turn every
+    // lane that has any candidate queues its lowest one.  The cluster mates of 32 consecutive rows sit on a tile's
+    // diagonal - 32 different lanes - so a tile takes one or two turns: 16 (sign words) + ~12 per turn vector
+    // instructions where round 2's register-by-register form issued ~250, most of that kernel's instructions.
+    // eps (slot positions follow queue order = ascending columns per row): register by register, but only the
+    // registers that hold a candidate in some lane (wave OR of the sign words), lanes in order.
+    // One copy of the loop (and of flush) for the four tiles of a super-tile.
+    auto push_signs = [&](u32 am0, u32 am1, u32 am2, u32 am3, int S, u32 tm) {   // tm: bit t = tile t is flagged
+      while (tm) {
+        const int t = __builtin_ctz(tm);
+        tm &= tm - 1u;
+        u32 a = t == 0 ? am0 : (t == 1 ? am1 : (t == 2 ? am2 : am3));
+        const u32 ebase = ((4u * (u32)(lane >> 5)) << SH) | (u32)((S * 4 + t) * 32 + (lane & 31));
+        if constexpr (MODE == PG_MODE_KNN) {
+          u64 mb = __builtin_amdgcn_ballot_w64(a != 0u);
+          while (mb) {
+            const u32 b = (u32)__builtin_ctz(a | 0x10000u); // register; its row: (b & 3) + 8 * (b >> 2) = b + (b & 12)
+            if (a != 0u) cq[qn + mask_rank(mb)] = ebase + ((b + (b & 12u)) << SH);
+            const int n = (int)__popcll(mb);
+            PG_ST(6, n);
+            PG_ST(20, 1);
+            qn += n;
+            a &= a - 1u;
+            if (qn >= 64) flush();                          // (at most 63 + 64 entries before it)
+            mb = __builtin_amdgcn_ballot_w64(a != 0u);
+          }
+        } else {
+          u32 regs = (u32)__builtin_amdgcn_readlane((int)wave_or_to63(a), 63);
+          while (regs) {
+            const u32 b = (u32)__builtin_ctz(regs);
+            regs &= regs - 1u;
+            const bool hit = (a >> b) & 1u;
+            const u64 mb = __builtin_amdgcn_ballot_w64(hit);
+            if (hit) cq[qn + mask_rank(mb)] = ebase + ((b + (b & 12u)) << SH);
+            const int n = (int)__popcll(mb);
+            PG_ST(6, n);
+            PG_ST(20, 1);
+            qn += n;
+            while (qn >= 64) flush();                       // (at most 63 + 64 entries before it)
           }
         }
-      } else {
-        done = 0;                                           // a crowded tile: register by register below
-      }
-      for (;;) {
-        if (done != 0xFFFFu) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if (((done >> r) & 1u) == 0 && qn < 64) {
-              done |= 1u << r;
-              const bool hit = d[r] < 0;
-              const u64 mb = __builtin_amdgcn_ballot_w64(hit);
-              if (mb) {
-                if (hit) cq[qn + mask_rank(mb)] = ebase + ((u32)((r & 3) + 8 * (r >> 2)) << SH);
-                qn += (int)__popcll(mb);
-              }
-            }
-          }
-        }
-        while (qn >= 64) flush();                           // the only flush site of the queueing code
-        if (done == 0xFFFFu) break;
       }
     };
-    pg_v4i ring[4];
-    int ringS = -1;                                         // super-tile whose fragments the ring holds
-    // one super-tile in the MFMA form; returns true when the signature is not selective here (nothing was queued)
-    auto sweep_mfma = [&](int S, int Snext) -> bool {
-      if (stale) refresh_bias();
-      if (ringS != S) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ring[i] = colsig[(long long)(S * 4 + i) * 64 + lane];
-      }
-      const pg_v4i *nx = colsig + (long long)Snext * 4 * 64 + lane;
-      // kNN keeps the fragments in the ring until the sign test is through: a super-tile with candidates (one in
-      // five at cfg3) evaluates its flagged tiles again without a trip to L2 (cfg3 3.50 -> 3.35 ms).  The eps
-      // instances, where such super-tiles are rarer, refill each register right after its MFMA - the earlier
-      // loads are worth more there (cfg3 eps <= 2: 2.83 against 3.00 ms) - and re-read the fragment.
-      constexpr bool kKeep = MODE == PG_MODE_KNN;
-      pg_v16i d0 = pg_mfma_fp4(A0, ring[0]);
-      if constexpr (!kKeep) ring[0] = nx[0];
-      pg_v16i d1 = pg_mfma_fp4(A0, ring[1]);
-      if constexpr (!kKeep) ring[1] = nx[64];
-      const int a0 = pg_or16(d0);
-      __builtin_amdgcn_sched_barrier(0);                    // two result sets in turn, not four (the 128-VGPR budget)
-      d0 = pg_mfma_fp4(A0, ring[2]);
-      if constexpr (!kKeep) ring[2] = nx[128];
-      const int a1 = pg_or16(d1);
-      __builtin_amdgcn_sched_barrier(0);
-      d1 = pg_mfma_fp4(A0, ring[3]);
-      if constexpr (!kKeep) ring[3] = nx[192];
-      const int a2 = pg_or16(d0);
-      const int a3 = pg_or16(d1);
-      ringS = Snext;
-      PG_ST(0, 1);
-      PG_ST(9, resweep);
-      if (!__builtin_amdgcn_ballot_w64((a0 | a1 | a2 | a3) < 0)) {
-        if constexpr (kKeep) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) ring[i] = nx[64 * i]; // the next super-tile's fragments (four loads in flight)
+    // The fragment ring: the column operands of one super-tile (4 x 1 KiB per wave).  It lives only inside scan().
+    // Its loads are inline assembly - destination = the ring register itself, so the hot loop has no copies at its
+    // back edge; address = the section's base (a kernel argument: always scalar) + a 32-bit vector offset (super-tile
+    // * 4096 + 16 * lane; the section is below 4 GiB: ncols < 2^27) + immediate - which the compiler does not count:
+    // the wait at the loop's head waits for them (the extra outstanding loads only make the compiler's own waits
+    // stricter).  RULE: between an assembly load and that wait there is no code in which the compiler could move or
+    // spill a ring register (it would read it before the data has landed): the loads are the last thing before it.
+    // HAZARD: "VALU writes an SGPR, a memory instruction reads it" needs five wait states, and nobody inserts them
+    // in front of inline assembly - while the compiler does hand over scalar operands it has just produced with
+    // v_readfirstlane (where it takes a loop for divergent) or v_readlane (an SGPR spill reload): that was a
+    // wrong-address fault.  So the base is copied by an s_mov INSIDE the statement (a scalar write has no such
+    // hazard), all four loads are ONE statement, and the moving part of the address is the vector offset.
+#define PG_RING_LOAD(c, voff)                                                                    \
+  asm volatile("s_mov_b64 %4, %6\n\t"                                                            \
+               "global_load_dwordx4 %0, %5, %4 offset:0\n\t"                                     \
+               "global_load_dwordx4 %1, %5, %4 offset:1024\n\t"                                  \
+               "global_load_dwordx4 %2, %5, %4 offset:2048\n\t"                                  \
+               "global_load_dwordx4 %3, %5, %4 offset:3072"                                      \
+               : c(r0), c(r1), c(r2), c(r3), "=&s"(ringBase) : "v"(voff), "s"(colsig) : "memory")
+    u32 am0 = 0, am1 = 0, am2 = 0, am3 = 0, amTiles = 0;    // scan() -> push_signs(): sign words of the flagged tiles
+    // THE HOT LOOP: super-tiles S, S+1, .. below `stop` in the MFMA form while none holds a candidate - four MFMAs on
+    // the ring, the OR of each result, one sign test, the ring refilled with the next super-tile's fragments.  A tight
+    // loop of its own: nothing of the slow paths' state lives in registers across it, no spill code inside.
+    // Returns 0: S reached `stop`;  1: super-tile S holds candidates, their sign words are in am0..3 / amTiles;
+    // 2: most lane slots of S hold a candidate - the signature is not selective here, the dense form takes over.
+    auto scan = [&](int &S, int stop) -> int {
+      u32 voff = ulane * 16u + (u32)S * 4096u;
+      pg_v4i r0, r1, r2, r3;
+      unsigned long long ringBase;                          // (scratch SGPR pair of the load statement)
+      PG_RING_LOAD("=&v", voff);
+      int a0, a1, a2, a3;
+      bool found;
+      for (;;) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");   // ring_wait
+#if defined(PG_MM_STATS) && defined(PG_MM_CHECK_RING)
+        {   // debug: the ring against ordinary loads of the same fragments
+          const pg_v4i *cp = colsig + (long long)S * 256;
+          const pg_v4i c0 = cp[ulane], c1 = cp[ulane + 64u], c2 = cp[ulane + 128u], c3 = cp[ulane + 192u];
+          const bool b0 = c0[0] != r0[0] || c0[1] != r0[1] || c0[2] != r0[2] || c0[3] != r0[3];
+          const bool b1 = c1[0] != r1[0] || c1[1] != r1[1] || c1[2] != r1[2] || c1[3] != r1[3];
+          const bool b2 = c2[0] != r2[0] || c2[1] != r2[1] || c2[2] != r2[2] || c2[3] != r2[3];
+          const bool b3 = c3[0] != r3[0] || c3[1] != r3[1] || c3[2] != r3[2] || c3[3] != r3[3];
+          if (__builtin_amdgcn_ballot_w64(b0)) PG_ST(22, 1);
+          if (__builtin_amdgcn_ballot_w64(b1 || b2 || b3)) PG_ST(23, 1);
         }
-        return false;
+#endif
+        pg_v16i d0 = pg_mfma_fp4(A0, r0);
+        pg_v16i d1 = pg_mfma_fp4(A0, r1);
+        __builtin_amdgcn_sched_barrier(0);                  // (two MFMAs in the pipe before the first OR)
+        a0 = pg_or16(d0);
+        __builtin_amdgcn_sched_barrier(0);                  // two result sets in turn, not four
+        d0 = pg_mfma_fp4(A0, r2);
+        a1 = pg_or16(d1);
+        __builtin_amdgcn_sched_barrier(0);
+        d1 = pg_mfma_fp4(A0, r3);
+        a2 = pg_or16(d0);
+        a3 = pg_or16(d1);
+        PG_ST(0, 1);
+        PG_ST(9, resweep);
+        found = __builtin_amdgcn_ballot_w64((a0 | a1 | a2 | a3) < 0) != 0;
+        if (found || S + 1 >= stop) break;                  // (the loop's one exit)
+        ++S;
+        voff += 4096u;
+        PG_RING_LOAD("+&v", voff);                          // the next super-tile's fragments (four loads in flight)
+      }
+      if (!found) {
+        ++S;
+        return 0;
       }
       PG_ST(1, 1);
       const u64 m0 = __builtin_amdgcn_ballot_w64(a0 < 0), m1 = __builtin_amdgcn_ballot_w64(a1 < 0);
       const u64 m2 = __builtin_amdgcn_ballot_w64(a2 < 0), m3 = __builtin_amdgcn_ballot_w64(a3 < 0);
       const int nslots = (int)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
-      if (nslots >= p.mmDenseL1) return true;               // most lane slots hold a candidate: the dense form takes over (ring dropped there)
-      if constexpr (kKeep) {
-        // (four copies of the queueing code: selecting the fragment by index instead cost 3x - the selects made
-        //  the compiler give up the ring's registers)
-        if (m0) { const pg_v16i d = pg_mfma_fp4(A0, ring[0]); ring[0] = nx[0]; queue_from(d, S * 4 + 0); } else ring[0] = nx[0];
-        if (m1) { const pg_v16i d = pg_mfma_fp4(A0, ring[1]); ring[1] = nx[64]; queue_from(d, S * 4 + 1); } else ring[1] = nx[64];
-        if (m2) { const pg_v16i d = pg_mfma_fp4(A0, ring[2]); ring[2] = nx[128]; queue_from(d, S * 4 + 2); } else ring[2] = nx[128];
-        if (m3) { const pg_v16i d = pg_mfma_fp4(A0, ring[3]); ring[3] = nx[192]; queue_from(d, S * 4 + 3); } else ring[3] = nx[192];
-      } else {
-        u32 tm = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
-        while (tm) {                                        // ascending tiles: queue order = column order per row
-          const int i = __builtin_ctz(tm);
-          tm &= tm - 1;
-          const int tile = S * 4 + i;
-          const pg_v16i d = pg_mfma_fp4(A0, colsig[(long long)tile * 64 + lane]);
-          queue_from(d, tile);
-        }
-      }
-      return false;
+#ifdef PG_MM_KNOBS
+      if (nslots >= K().mmDenseL1) return 2;                // (tuning builds: PG_MM_L1 at run time)
+#else
+      if (nslots >= PG_MM_DENSE_L1) return 2;
+#endif
+      am0 = m0 ? signs16(pg_mfma_fp4(A0, r0)) : 0u;         // the flagged tiles again, from the ring
+      am1 = m1 ? signs16(pg_mfma_fp4(A0, r1)) : 0u;
+      am2 = m2 ? signs16(pg_mfma_fp4(A0, r2)) : 0u;
+      am3 = m3 ? signs16(pg_mfma_fp4(A0, r3)) : 0u;
+      amTiles = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
+      return 1;
     };
 
     // ---- dense forms (the signature is not selective: mutant libraries, one cluster) ----
@@ -524,7 +661,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // A run starts in the folded form and falls back to `exact` where the bound is not selective (hits in three
     // lanes of four, or more than 16 candidates a row: bounds still loose, eps graphs of data this dense,
     // unrelated sequences), probing again after 16 .. 256 super-tiles.
-    constexpr int G = M::kGroups, B = M::kBits;
+    constexpr int B = M::kBits;
     constexpr int CF = 4;                                   // folded form: columns per lane
     // plane folds of sequences come from the fold section of the plane buffer (pg_pack_planes): the columns'
     // as per-lane loads (B words a column), the rows' as SCALAR loads - wave-uniform addresses in the
@@ -658,9 +795,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       if constexpr (MODE == PG_MODE_KNN) {
         // the hits, lane-parallel: per slice every lane that holds any queues its lowest one, until none is left
         // (one or two turns as a rule; the order of a row's candidates does not matter to its list)
-#pragma unroll
+#pragma nounroll
         for (int b = 0; b < CF; ++b) {
-          u32 a = acc[b];
+          u32 a = b == 0 ? acc[0] : (b == 1 ? acc[1] : (b == 2 ? acc[2] : acc[3]));
           u64 mb = __builtin_amdgcn_ballot_w64(a != 0);
           while (mb) {
             const u32 j = (u32)__builtin_ctz(a | 0x80000000u);
@@ -680,9 +817,10 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           const int j = __builtin_ctz(rowsHit);
           rowsHit &= rowsHit - 1;
           const u32 erow = (u32)(np - 1 - j) << SH;
-#pragma unroll
+#pragma nounroll
           for (int b = 0; b < CF; ++b) {
-            const bool hit = (acc[b] >> j) & 1u;
+            const u32 ab = b == 0 ? acc[0] : (b == 1 ? acc[1] : (b == 2 ? acc[2] : acc[3]));
+            const bool hit = (ab >> j) & 1u;
             const u64 mb = __builtin_amdgcn_ballot_w64(hit);
             if (mb) {
               if (hit) cq[qn + mask_rank(mb)] = erow | ((u32)colbase + b * 64 + lane);
@@ -702,31 +840,36 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // kNN checkpoints (first super-tile after them): after 1/32 of the sweep a row without any near
     // column yet is taken to be unclustered and loses the cap; after 1/8 every row whose list is
     // not settled below G0 does.  Phase 1 covers the larger range in use.
-    auto checkpoint = [&](int sprev, int snext) {            // the sweep went from super-tile sprev to snext
+    // `nextCk` = the super-tile at (or after) which the next checkpoint is due; the sweep loop below services it -
+    // queue drained first - at the first position it reaches from there (the one site shared with the end-of-sweep
+    // drain: one copy of flush).  No checkpoints without a cap and in phase 1.
+    constexpr int kNoCk = 0x7FFFFFFF;
+    int nextCk = (MODE == PG_MODE_KNN && G0) ? ((nst + 31) >> 5) : kNoCk;
+    auto checkpoint = [&](int snext) {                      // the sweep has reached super-tile snext >= nextCk; queue empty
       if constexpr (MODE == PG_MODE_KNN) {
-        const int sw1 = (nst + 31) >> 5, sw2 = (nst + 7) >> 3;
-        const bool at1 = sprev < sw1 && sw1 <= snext, at2 = sprev < sw2 && sw2 <= snext;
-        if (G0 && !resweep && (at1 || at2)) {
-          while (qn > 0) flush();
-          const bool mine = lane < nr && !((failed >> (lane & 31)) & 1);
-          u32 dref = thrv >> 24;                             // open lists read 255
-          if (!at2) dref = mine ? lstbuf[wv][lane & 31][p.knnFirst] >> 24 : 0u;
-          const bool late = mine && dref >= G0;
-          const u32 now = (u32)__builtin_amdgcn_ballot_w64(late);   // rows < 32
-          if (now) {
-            failed |= now;
-            sredo = snext;
-            if (late) capv = 255u;
-            const u32 b = thrv >> 24;
-            set_all_bounds(lane < nr ? (b < capv ? b : capv) : 0u);
-          }
+        const int sw2 = (nst + 7) >> 3;
+        const bool at2 = snext >= sw2;
+        nextCk = at2 ? kNoCk : sw2;
+        const bool mine = lane < nr && !((failed >> (lane & 31)) & 1);
+        u32 dref = thrv >> 24;                             // open lists read 255
+        if (!at2) dref = mine ? lstbuf[wv][lane & 31][lfirst] >> 24 : 0u;
+        const bool late = mine && dref >= G0;
+        const u32 now = (u32)__builtin_amdgcn_ballot_w64(late);   // rows < 32
+        if (now) {
+          failed |= now;
+          sredo = snext;
+          if (late) capv = 255u;
+          const u32 b = thrv >> 24;
+          set_all_bounds(lane < nr ? (b < capv ? b : capv) : 0u);
         }
       }
     };
     const bool canFold = canFilter;                         // PG_LB_FILTER=0 (or too many columns for queue entries): exact form only
     bool prefilter = canFold;
     int exact_left = 0, exact_run = 16;
-    auto run_dense = [&](int S0, int S1) -> int {           // super-tiles [S0, S1); returns where it stopped (>= S1)
+    // super-tiles [S0, S1); returns where it stopped: >= S1 (a folded tile may end one past it), or earlier at a
+    // position >= nextCk (a checkpoint is due: the caller services it and calls again)
+    auto run_dense = [&](int S0, int S1) -> int {
       constexpr int F = PG_MM_ST / (64 * C);                // exact tiles per super-tile
       int s = S0;
       while (s < S1) {
@@ -745,10 +888,10 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
               break;
             }
             s += 2;
-            checkpoint(s - 2, s);
             exact_run = 16;
             // a candidate costs about three instructions of a gather batch, an exact row-step 25 per 64 columns
             if (ncand > 16 * nr) { prefilter = false; exact_left = 16; break; }
+            if (s >= nextCk) return s;
 #pragma unroll
             for (int b = 0; b < CF; ++b)
 #pragma unroll
@@ -756,21 +899,22 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           }
         } else {
           // exact form: to the end of the run, or until the bound is due for another probe
-          while (qn > 0) flush();                           // in-place results must come after queued ones
+          if constexpr (kEps) {
+            while (qn > 0) flush();                         // in-place results must come after queued ones (slot order)
+          }
           int s1 = S1;
           if (prefilter) s1 = s + 1;                        // an odd super-tile in front of the folded tiles
           else if (canFold && s + exact_left < S1) s1 = s + exact_left;
+          if (s < nextCk && nextCk < s1) s1 = nextCk;       // a run ends where a checkpoint is due
           const int t0 = s * F, t1 = s1 * F;
           uint4 ca[C][Q], cb[C][Q];
           load_cols(ca, t0);
           for (int dt = t0; dt < t1; dt += 2) {
             load_cols(cb, dt + 1 < t1 ? dt + 1 : dt);
             rows_exact(ca, dt);
-            if ((dt + 1) % F == 0) checkpoint((dt + 1) / F - 1, (dt + 1) / F);
             if (dt + 1 < t1) {
               load_cols(ca, dt + 2 < t1 ? dt + 2 : dt + 1);
               rows_exact(cb, dt + 1);
-              if ((dt + 2) % F == 0) checkpoint((dt + 2) / F - 1, (dt + 2) / F);
             }
           }
           if (!prefilter && canFold) {
@@ -778,20 +922,41 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
             if (exact_left <= 0) prefilter = true;
           }
           s = s1;
+          if (s >= nextCk) return s;
         }
       }
       return s;
     };
 
+    PG_T1(21, tp0);
     int send = nst;
     int drun = 0;                                           // super-tiles per dense run (0: the first of a series)
     const int sbeg = kSym ? (int)(pr0 / PG_MM_ST) : 0;     // EPS_SYM: from the super-tile that holds the pass's first row
     for (;;) {
       int S = sbeg;
-      if (!canFilter) S = run_dense(S, send);               // no filter: the exact form throughout
-      while (S < send) {
-        if (!sweep_mfma(S, S + 1 < send ? S + 1 : S)) {     // the common case: the MFMA form did the super-tile
-          checkpoint(S, S + 1);
+      int dEnd = canFilter ? 0 : send;                      // a dense run is in progress up to here (no filter: throughout)
+      for (;;) {
+        if (S >= send || S >= nextCk) {                     // end of the sweep / a checkpoint: the queue is drained HERE
+          while (qn > 0) flush();
+          if (S >= nextCk) checkpoint(S);
+          if (S >= send) break;
+        }
+        if (S < dEnd) {
+          S = run_dense(S, dEnd);                           // (returns early where a checkpoint is due)
+          continue;
+        }
+        if (stale) { PG_ST(19, 1); refresh_bias(); }
+        const int Sin = S;
+        PG_ST(18, 1);
+        PG_T0(ts0);
+        const int rc = scan(S, send < nextCk ? send : nextCk);
+        PG_T1(16, ts0);
+        if (S != Sin) drun = 0;                             // a clean stretch ends a series of dense runs
+        if (rc == 0) continue;
+        if (rc == 1) {                                      // candidates queued, the MFMA form goes on
+          PG_T0(tq0);
+          push_signs(am0, am1, am2, am3, S, amTiles);
+          PG_T1(17, tq0);
           ++S;
           drun = 0;
           continue;
@@ -799,23 +964,18 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         // the signature is not selective here: a run of the dense form
         const int drun0 = K().mmDirectRun;
         if (!drun) drun = drun0;
-        const int S1 = S + drun < send ? S + drun : send;
+        dEnd = S + drun < send ? S + drun : send;
         drun = drun * 2 < 8 * drun0 ? drun * 2 : 8 * drun0;  // back off while every probe is dense
-        ringS = -1;                                         // the fragments prefetched before the run are stale:
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ring[i] = pg_v4i{0, 0, 0, 0};   // dead across the run (frees their registers there)
         PG_ST(3, 1);
-        PG_ST(4, S1 - S);
-        S = run_dense(S, S1);                               // checkpoints inside; a folded tile may end one past S1
+        PG_ST(4, dEnd - S);
       }
-      while (qn > 0) flush();
       if constexpr (MODE == PG_MODE_KNN) {
         if (!failed || resweep) break;
         // phase 1: the rows that lost their cap see super-tiles [0, sredo) again; the others are frozen
         resweep = 1;
+        nextCk = kNoCk;
         set_all_bounds((lane < nr && ((failed >> (lane & 31)) & 1)) ? (thrv >> 24) + 1u : 0u);
         send = sredo;
-        ringS = -1;
       } else {
         break;
       }
@@ -826,14 +986,26 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       if (lane < nr) p.counts[pr0 + lane] = cntv;
     } else {
       const auto &kr = K();
-      for (int rr = 0; rr < nr; ++rr) {
-        const u32 key = lstbuf[wv][rr][lane];
-        if (lane >= kr.knnFirst && lane < kr.knnFirst + kr.k) {
-          const long long o = (pr0 + rr) * (long long)kr.k + (lane - kr.knnFirst);
+      if constexpr (kPar) {
+        // the pass's nr x k results are one contiguous stretch of the output: coalesced stores
+        const int kk = kr.k;
+        for (int e = lane; e < nr * kk; e += 64) {
+          const int rr = e / kk, j = e - rr * kk;
+          const u32 key = lstbuf[wv][rr][KL - kk + j];
+          const long long o = pr0 * (long long)kk + e;
           kr.knnIdx[o] = (key == 0xFFFFFFFFu) ? -1 : (int)(key & 0x00FFFFFFu);
           kr.knnDist[o] = (unsigned char)(key >> 24);
         }
-        if (kr.lastKeys && lane == thrLane) kr.lastKeys[pr0 + rr] = key;
+      } else {
+        for (int rr = 0; rr < nr; ++rr) {
+          const u32 key = lstbuf[wv][rr][lane];
+          if (lane >= kr.knnFirst && lane < kr.knnFirst + kr.k) {
+            const long long o = (pr0 + rr) * (long long)kr.k + (lane - kr.knnFirst);
+            kr.knnIdx[o] = (key == 0xFFFFFFFFu) ? -1 : (int)(key & 0x00FFFFFFu);
+            kr.knnDist[o] = (unsigned char)(key >> 24);
+          }
+          if (kr.lastKeys && lane == thrLane) kr.lastKeys[pr0 + rr] = key;
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -841,8 +1013,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     PG_T1(15, tp0);
 #ifdef PG_MM_STATS
     if (p.stats && lane == 0 && pass < 65536) {
-      p.stats[16 + 2 * pass] = tr0;                    // 100 MHz wall clock at the start of the pass
-      p.stats[16 + 2 * pass + 1] = (__builtin_amdgcn_s_memrealtime() - tr0) | ((unsigned long long)(st[5] - st5_0) << 24) |
+      p.stats[PG_NSTAT + 2 * pass] = tr0;              // 100 MHz wall clock at the start of the pass
+      p.stats[PG_NSTAT + 2 * pass + 1] = (__builtin_amdgcn_s_memrealtime() - tr0) | ((unsigned long long)(st[5] - st5_0) << 24) |
                                          ((unsigned long long)(st[2] - st2_0) << 44) | ((unsigned long long)(st[7] - st7_0) << 54);
     }
 #endif
@@ -855,8 +1027,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   {
     u32 v = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v = lane == i ? st[i] : v;
-    if (p.stats && lane < 16) atomicAdd(&p.stats[lane], (unsigned long long)v);
+    for (int i = 0; i < PG_NSTAT; ++i) v = lane == i ? st[i] : v;
+    if (p.stats && lane < PG_NSTAT) atomicAdd(&p.stats[lane], (unsigned long long)v);
   }
 #endif
 }

@@ -1,4 +1,4 @@
-"""A/B timing of several builds of libprograph_hip.so on one box: tools/ab.py libA.so libB.so ...
+"""A/B timing of several builds of libprograph_hip.so on one box: tools/ab.py libA.so libB.so[:ENV=VAL,ENV=VAL] ...
 Each build runs in its own child process (PROGRAPH_HIP_LIB), the rounds are interleaved."""
 import os, subprocess, sys
 
@@ -29,7 +29,10 @@ print(" ".join("%%s%%d/%%d/%%d=%%.3f" %% (m, N, L, b, run(N, L, b, m)) for N, L,
 
 libs = sys.argv[1:]
 for rnd in range(2):
-    for lib in libs:
+    for spec in libs:
+        lib, _, extra = spec.partition(":")
         env = dict(os.environ, PROGRAPH_HIP_LIB=os.path.abspath(lib))
+        for kv in filter(None, extra.split(",")):
+            env[kv.split("=")[0]] = kv.split("=", 1)[1]
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
-        print(f"[{os.path.basename(lib)}] {out.stdout.strip()} {out.stderr.strip()[-300:] if out.returncode else ''}", flush=True)
+        print(f"[{os.path.basename(spec)}] {out.stdout.strip()} {out.stderr.strip()[-300:] if out.returncode else ''}", flush=True)

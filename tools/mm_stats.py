@@ -11,10 +11,13 @@ from prograph_amd import _native as nat, synth
 
 NAMES = ["L1 super-tiles", "with candidates", "dense tiles, every distance", "dense runs", "dense super-tiles", "dense row-steps past the bound",
          "candidates queued", "flushes", "insertions/matches", "resweep super-tiles", "passes", "dense tiles, folded bound",
-         "x64 cycles in flush", "x64 cycles in kNN insertion loops", "x64 cycles in folded tiles (incl. their flushes)", "x64 cycles in passes"]
+         "x64 cycles in flush", "x64 cycles in kNN insertion loops", "x64 cycles in folded tiles (incl. their flushes)", "x64 cycles in passes",
+         "x64 cycles in scan (hot loop)", "x64 cycles in slow_mfma (incl. its flushes)", "scan calls", "bias refreshes", "queueing turns",
+         "x64 cycles of pass setup", "-", "-"]
+NST = 24
 lib = nat.lib()
 def stats(reset=True):
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * NST)()
     lib.pg_debug_stats(buf, 1 if reset else 0)
     return list(buf)
 def timed(f):
@@ -35,7 +38,10 @@ for name in (sys.argv[1:] or ["cfg3", "dense", "random"]):
     si = torch.empty(N * cap, dtype=torch.int32, device=dev); sw = torch.empty(N * cap, dtype=torch.uint8, device=dev)
     cnt = torch.empty(N, dtype=torch.int32, device=dev)
     out = (torch.empty((N, 16), dtype=torch.int32, device=dev), torch.empty((N, 16), dtype=torch.uint8, device=dev))
+    whats = os.environ.get("MM_STATS_WHAT", "knn16,eps2").split(",")
     for what, f in (("knn16", lambda: nat.knn_graph(p, p, 16, out=out)), ("eps2", lambda: nat.eps_slots_only(p, p, nat.CMP_LE, 2, 0, N, cap, si, sw, cnt))):
+        if what not in whats:
+            continue
         ms, st = timed(f)
         print(f"== {name} {what}: {ms:.3f} ms")
         for n, v in zip(NAMES, st):

@@ -15,9 +15,9 @@ for name in (sys.argv[1:] or ["dense"]):
     nat.knn_graph(p, p, 16, out=out); torch.cuda.synchronize()
     lib.pg_debug_stats(None, 1)
     nat.knn_graph(p, p, 16, out=out); torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * (16 + 2 * 65536))()
+    buf = (ctypes.c_ulonglong * (24 + 2 * 65536))()
     lib.pg_debug_stats(buf, 3)
-    raw = np.frombuffer(buf, dtype=np.uint64)[16:].reshape(-1, 2)
+    raw = np.frombuffer(buf, dtype=np.uint64)[24:].reshape(-1, 2)
     raw = raw[raw[:, 0] != 0]
     cand = ((raw[:, 1] >> np.uint64(24)) & np.uint64(0xFFFFF)).astype(np.float64); exact = ((raw[:, 1] >> np.uint64(44)) & np.uint64(0x3FF)).astype(np.float64); flushes = (raw[:, 1] >> np.uint64(54)).astype(np.float64)
     a = np.stack([raw[:, 0].astype(np.float64), (raw[:, 1] & np.uint64(0xFFFFFF)).astype(np.float64)], axis=1)
