@@ -522,27 +522,27 @@ static const nsq_fn kMm[8] = {pg_launch_mm_g1, pg_launch_mm_g2, pg_launch_mm_g3,
 // slower (dense 200k: 12.5 -> 14.1 ms, cfg3 3.81 -> 3.90) - a round of 2154 full passes on half-empty SIMDs runs
 // faster per pass than 3830 passes of 18 rows on full ones - and therefore off.
 // PG_ROWS_PER_WAVE = uniform passes of that many rows (tuning sweeps).
-static void plan_mm(int64_t nrows, NsqParams *p, int *grid) {
-  long long rpw = PG_MM_RB, tailFrom = (nrows + PG_MM_RB - 1) / PG_MM_RB, tailRows = PG_MM_RB;
+static void plan_mm(int64_t nrows, NsqParams *p, int *grid, int rb = PG_MM_RB) {   // rb: rows per pass of the instance (32 or 64)
+  long long rpw = rb, tailFrom = (nrows + rb - 1) / rb, tailRows = rb;
   const long long slots = (long long)(cu_count() > 0 ? cu_count() : 256) * 16;
   const char *e = getenv("PG_ROWS_PER_WAVE");
   const char *t = getenv("PG_MM_TAIL");
   if (e && atoi(e) > 0) {
-    rpw = atoi(e) < PG_MM_RB ? atoi(e) : PG_MM_RB;          // (a wave sweeps one pass of at most 32 rows at a time)
+    rpw = atoi(e) < rb ? atoi(e) : rb;                      // (a wave sweeps one pass of at most rb rows at a time)
     tailFrom = (nrows + rpw - 1) / rpw; tailRows = rpw;
   } else {
-    const long long full = nrows / (slots * PG_MM_RB) * slots;          // passes of the full rounds
-    const long long rest = nrows - full * PG_MM_RB;
+    const long long full = nrows / (slots * rb) * slots;                // passes of the full rounds
+    const long long rest = nrows - full * rb;
     if (rest > 0 && (full == 0 || (t && atoi(t) == 1))) {
       long long r = (long long)((double)rest / (0.97 * (double)slots)) + 1;
       r = (r + 1) / 2 * 2;
       if (r < 4) r = 4;
-      if (r > PG_MM_RB) r = PG_MM_RB;
+      if (r > rb) r = rb;
       if (full == 0 && r < 16) r = 16;                                  // a single round: at least half-filled MFMA tiles
       tailFrom = full; tailRows = r;
     }
   }
-  p->rowsPerWave = (int)rpw; p->rowsPerPass = PG_MM_RB;
+  p->rowsPerWave = (int)rpw; p->rowsPerPass = rb;
   p->mmTailFrom = tailFrom; p->mmTailRows = (int)tailRows;
   const long long headRows = tailFrom * rpw < nrows ? tailFrom * rpw : nrows;
   const long long waves = tailFrom + (nrows - headRows + tailRows - 1) / tailRows;
@@ -732,14 +732,19 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;
   if (use_mm_engine(nrows)) {
-    plan_mm(nrows, &p, &grid);
-    if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
     // short lists (the usual k): the instance that inserts a whole batch of candidates at once (pg_mm.h, KL).
     // PG_MM_SHORT=0 keeps the 64-lane lists (A/B runs)
     const bool shortList = first == 1 && k + 1 <= PG_MM_KL && !floor_keys && !last_keys &&
                            !(getenv("PG_MM_SHORT") && atoi(getenv("PG_MM_SHORT")) == 0);
-    return launched(kMm[pg_ngroups(l) - 1](shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN, bits, p, grid, (hipStream_t)stream),
-                    "pg_mm_kernel(knn)");
+    // ... with 64 rows per pass (every column fragment feeds two MFMAs: half the vector-memory traffic per pair)
+    // where passes of 64 still fill most of the chip's wave slots; PG_MM_R=1 / 2 forces either
+    const long long slots = (long long)(cu_count() > 0 ? cu_count() : 256) * 16;
+    bool two = shortList && nrows >= 64 * slots * 6 / 10;
+    if (const char *e = getenv("PG_MM_R")) two = shortList && atoi(e) == 2;
+    plan_mm(nrows, &p, &grid, two ? 2 * PG_MM_RB : PG_MM_RB);
+    if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
+    return launched(kMm[pg_ngroups(l) - 1](two ? PG_MODE_KNN_SHORT2 : (shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN), bits, p, grid,
+                                           (hipStream_t)stream), "pg_mm_kernel(knn)");
   }
   if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits), 16.0 * pg_nchunks(l, bits), PG_RB_KNN)) return rc;
   return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");

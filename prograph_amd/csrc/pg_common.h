@@ -24,6 +24,7 @@ typedef unsigned long long u64;
 
 enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1, PG_MODE_EPS_SYM = 2 };   // EPS_SYM: square self-graph, upper triangle only
 #define PG_MODE_KNN_SHORT 3   // launcher code only: pg_mm_kernel<.., PG_MODE_KNN, PG_MM_KL> (k + 1 <= PG_MM_KL, ranks from 1)
+#define PG_MODE_KNN_SHORT2 4  // the same with two row blocks (64 rows) per pass: pg_mm_kernel<.., PG_MODE_KNN, PG_MM_KL, 2>
 #ifndef PG_MM_KL
 #define PG_MM_KL 20           // list entries of the short-list kNN instance of pg_mm.h (a multiple of 4)
 #endif

@@ -55,6 +55,9 @@ typedef int pg_v16i __attribute__((ext_vector_type(16)));
 #define PG_MM_DENSE_L2 48    // (unused since the MFMA level 2 was dropped; NsqParams still carries the field)
 #define PG_MM_GROUP_ROWS 4    // folded form: rows per group of straight-line code (their folds: 20 SGPRs in flight)
 #define PG_MM_DIRECT_RUN 8   // super-tiles of dense form before the MFMA filter is probed again
+#ifndef PG_EXP_SAMETILE
+#define PG_EXP_SAMETILE 0   // experiment builds: 1 = every fragment load reads the same super-tile (L1 hits; wrong results)
+#endif
 #define PG_NSTAT 24          // debug builds (-DPG_MM_STATS): event / cycle counters per launch, then (start, duration) per pass
 
 static_assert(PG_MM_QCAP >= 63 + 64, "a register push adds up to 64 candidates to a queue holding up to 63");
@@ -106,20 +109,25 @@ __device__ __forceinline__ int pg_or16(const pg_v16i &d) {
 // dwords, RIGHT aligned (the (k+1)-th smallest key, i.e. the row's threshold, is always entry KL-1; unused entries in
 // front hold 0), and a flush inserts up to 64 candidates of different rows AT ONCE, one per lane: the winner lane of a row
 // reads its list (KL/4 ds_read_b128), new[i] = med3(old[i-1], key, old[i]), writes it back.
-template <class M, int MODE, int KL = 64>
+// R: row blocks of 32 per pass (1 or 2).  The hot loop is bound by the vector-memory return path (64 B per clock and
+// CU: every MFMA needs a fresh 1 KiB fragment; measured ~70 % of that rate, with the loads hitting L1 or L2 alike), so
+// R = 2 - two row operands, every fragment feeds two MFMAs - halves that traffic per pair.  Per-row state is lane
+// indexed, a wave has 64 lanes: R <= 2.  Short lists only (LDS).
+template <class M, int MODE, int KL = 64, int R = 1>
 __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M::Q <= 3 ? 4 : 1, 8))) void pg_mm_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
   constexpr bool kPar = MODE == PG_MODE_KNN && KL < 64;    // lane-per-candidate insertion
   static_assert(KL == 64 || (KL % 4 == 0 && KL >= 8 && KL <= 32), "list entries: 64, or a multiple of 4 in 8..32");
+  static_assert(R == 1 || (R == 2 && kPar), "two row blocks per pass: the short-list kNN instance only");
   constexpr int C = Q <= 4 ? 2 : 1;                        // direct form: columns per lane
   constexpr bool kEps = MODE != PG_MODE_KNN;
   constexpr bool kSym = MODE == PG_MODE_EPS_SYM;
-  constexpr int RB = PG_MM_RB;
+  constexpr int RB = PG_MM_RB * R;
   constexpr int LROWS = MODE == PG_MODE_KNN ? RB : 1;
   __shared__ uint4 rowbuf[PG_WG_WAVES][RB][Q];
   __shared__ __attribute__((aligned(16))) u32 lstbuf[PG_WG_WAVES][LROWS][KL];   // kNN: per row the sorted keys (see KL above)
   __shared__ u32 cqbuf[PG_WG_WAVES][PG_MM_QCAP];           // deferred candidates: row << SH | column
-  __shared__ u32 claimbuf[PG_WG_WAVES][kPar ? 32 : 1];     // kPar: per row the lane that inserts in this turn
+  __shared__ u32 claimbuf[PG_WG_WAVES][kPar ? RB : 1];     // kPar: per row the lane that inserts in this turn
   const int lane = threadIdx.x & 63;
   const u32 ulane = (u32)lane;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       return (long long)(((unsigned long long)hi32 << 32) | (unsigned long long)lo32);
     };
     const u32 G0 = (MODE == PG_MODE_KNN && canFilter) ? p.knnGuess : 0u;
-    u32 failed = 0;                                         // kNN: rows that lost their optimistic cap (bit = row, all 32 bits in use)
+    u64 failed = 0;                                         // kNN: rows that lost their optimistic cap (bit = row)
     u32 resweep = 0;                                        // kNN: 1 in phase 1 (early super-tiles again for the failed rows)
     int sredo = 0;                                          // kNN: super-tiles [0, sredo) are swept again for them
     // list geometry: lanes / entries [lfirst, lfirst + k) are written out, entry thrLane is the row's threshold
@@ -231,42 +239,52 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // ---- row operand of the MFMA: lane l holds row l & 31, elements k = 32*(l >> 5) .. +31 as FP4 nibbles:
     // signature bit set -> -1.0 (0xA), clear -> +1.0 (0x2); k = 54..63 (top byte of A0[2] and A0[3] of lanes
     // 32..) = the bias pa - bound as a sum of up to ten elements, so D = lb - bound and its sign is the answer ----
-    u32 pa0;
-    pg_v4i A0;
-    {
+    // (named scalars per row block, not arrays: an array indexed inside a loop the compiler unrolls late ends up in
+    //  scratch memory; block 1 is dead code for R == 1)
+    u32 pa0 = 0, pa1 = 0;
+    pg_v4i A0 = {0, 0, 0, 0}, A1 = {0, 0, 0, 0};            // block b: rows 32b .. 32b+31 of the pass
+    auto build_operand = [&](int blk, u32 &pa, pg_v4i &A) {
       uint4 rec[Q];
 #pragma unroll
-      for (int q = 0; q < Q; ++q) rec[q] = rowbuf[wv][lane & 31][q];
+      for (int q = 0; q < Q; ++q) rec[q] = rowbuf[wv][32 * blk + (lane & 31)][q];
       u32 even, odd;
       M::fold2(rec, even, odd);
       const unsigned long long sig = pg_sig54(even, odd);
-      pa0 = (u32)__builtin_popcountll(sig);
+      pa = (u32)__builtin_popcountll(sig);
       const u32 half = lane >> 5 ? (u32)(sig >> 32) : (u32)sig;
-      A0[0] = (int)(0x22222222u | (pg_nib8(half) << 3));
-      A0[1] = (int)(0x22222222u | (pg_nib8(half >> 8) << 3));
-      A0[2] = (int)(0x22222222u | (pg_nib8(half >> 16) << 3));
-      A0[3] = (int)(0x22222222u | (pg_nib8(half >> 24) << 3));
-    }
-    // A row's bound: lanes 32.. hold it in boundv (authoritative) and as bias nibbles in their operand.
+      A[0] = (int)(0x22222222u | (pg_nib8(half) << 3));
+      A[1] = (int)(0x22222222u | (pg_nib8(half >> 8) << 3));
+      A[2] = (int)(0x22222222u | (pg_nib8(half >> 16) << 3));
+      A[3] = (int)(0x22222222u | (pg_nib8(half >> 24) << 3));
+    };
+    build_operand(0, pa0, A0);
+    if constexpr (R == 2) build_operand(1, pa1, A1);
+    // A row's bound: lanes 32.. of its block's boundv hold it (authoritative) and, as bias nibbles, their operand.
     // A bound beyond pa + 60 passes everything either way (lb <= 54).  A bound that moves (kNN: always down)
-    // only marks the operand stale; the next super-tile of the MFMA form re-encodes all rows at once - one
+    // only marks the operand stale; the next stretch of the MFMA form re-encodes all rows at once - one
     // copy of the encoder, one pass per flush instead of one per insertion; a stale bias is merely looser.
-    u32 boundv = 0;
+    u32 boundv0 = 0, boundv1 = 0;
     bool stale = false;
-    auto refresh_bias = [&]() {
-      const unsigned long long nb = pg_bias_nibbles(boundv > 255u ? -60 : (int)pa0 - (int)boundv);
+    auto encode_bias = [&](u32 pa, u32 bound, pg_v4i &A) {
       const bool up = lane >= 32;
-      A0[2] = up ? (int)(((u32)A0[2] & 0x00FFFFFFu) | ((u32)nb << 24)) : A0[2];
-      A0[3] = up ? (int)(u32)(nb >> 8) : A0[3];
+      const unsigned long long nb = pg_bias_nibbles(bound > 255u ? -60 : (int)pa - (int)bound);
+      A[2] = up ? (int)(((u32)A[2] & 0x00FFFFFFu) | ((u32)nb << 24)) : A[2];
+      A[3] = up ? (int)(u32)(nb >> 8) : A[3];
+    };
+    auto refresh_bias = [&]() {
+      encode_bias(pa0, boundv0, A0);
+      if constexpr (R == 2) encode_bias(pa1, boundv1, A1);
       stale = false;
     };
     auto set_bound = [&](int row, u32 bound) {              // row, bound wave uniform
-      boundv = (lane == 32 + row) ? bound : boundv;
+      boundv0 = (row < 32 && lane == 32 + row) ? bound : boundv0;
+      if constexpr (R == 2) boundv1 = (row >= 32 && lane == row) ? bound : boundv1;
       stale = true;
     };
-    auto set_all_bounds = [&](u32 bv) {                     // bv: lane r < 32 holds row r's bound
-      boundv = (u32)__builtin_amdgcn_ds_bpermute((lane & 31) << 2, (int)bv);
-      stale = true;                                         // (may loosen bounds: every caller is followed by sweep_mfma's refresh)
+    auto set_all_bounds = [&](u32 bv) {                     // bv: lane r < RB holds row r's bound
+      boundv0 = (u32)__builtin_amdgcn_ds_bpermute((lane & 31) << 2, (int)bv);
+      if constexpr (R == 2) boundv1 = (u32)__builtin_amdgcn_ds_bpermute(((lane & 31) + 32) << 2, (int)bv);
+      stale = true;                                         // (may loosen bounds: the refresh comes before the next scan)
     };
 
     // Per-row state, lane indexed (lane = row in pass), touched with v_readlane / lane selects:
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // kNN: the bounds of ALL rows from the row-indexed state (after a flush that moved several thresholds at once):
     // min(threshold distance [+1 in phase 1], cap); 0 for rows past nr and, in phase 1, for the frozen rows
     auto republish_all = [&]() {
-      const bool live = lane < nr && (!resweep || ((failed >> (lane & 31)) & 1u));
+      const bool live = lane < nr && (!resweep || ((failed >> lane) & 1ull));
       const u32 b = (thrv >> 24) + resweep;                 // open lists read 255
       set_all_bounds(live ? (b < capv ? b : capv) : 0u);
     };
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         // candidates of one row take turns (the row's claim word says whose turn it is; any order gives the same
         // list: keys are totally ordered).
         const u32 col = e & 0x00FFFFFFu;
-        const u32 erow = (e >> 24) & 31u;
+        const u32 erow = (e >> 24) & (u32)(RB - 1);
         const bool act = lane < nbat && col < ncols;
         u32 key = 0xFFFFFFFFu;
         if (act) {
@@ -376,9 +394,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           for (int q = 0; q < Q; ++q) rw[q] = rowbuf[wv][erow][q];
           key = (M::dist(rw, cr, 0u) << 24) | col;
         }
-        const u32 thr0 = (u32)__builtin_amdgcn_ds_bpermute((int)(erow << 2), (int)thrv);
-        bool pend = act && key < thr0;
-        bool moved = false;                                 // the threshold DISTANCE of this lane's row changed
+        bool pend = act && key < lstbuf[wv][erow][KL - 1];  // (a row's threshold is the last entry of its list)
         PG_T0(ti0);
         while (__builtin_amdgcn_ballot_w64(pend)) {
           // (LDS operations of a wave are processed in order: the last writer of a row's word wins.  The fences keep
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           const bool win = pend && claimbuf[wv][erow] == (u32)lane;
-          u32 nthr = 0u;
+          [[maybe_unused]] bool ins = false;
           if (win) {
             uint4 *lp = reinterpret_cast<uint4 *>(&lstbuf[wv][erow][0]);
             u32 o[KL];
@@ -398,8 +414,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
               const uint4 v = lp[i];
               o[4 * i] = v.x; o[4 * i + 1] = v.y; o[4 * i + 2] = v.z; o[4 * i + 3] = v.w;
             }
-            const u32 othr = o[KL - 1];
-            bool ok = key < othr;                           // (the row's threshold may have moved on since thr0 was read)
+            bool ok = key < o[KL - 1];                      // (the row's threshold may have moved on since the first look)
             if (resweep) {                                  // phase 1 meets columns again: no duplicates
               bool dup = false;
 #pragma unroll
@@ -412,17 +427,19 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
               o[0] = o[0] < key ? o[0] : key;
 #pragma unroll
               for (int i = 0; i < KL / 4; ++i) lp[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
-              nthr = o[KL - 1];
-              moved = moved || (nthr >> 24) != (othr >> 24);
+              ins = true;
             }
           }
-          PG_ST(8, __popcll(__builtin_amdgcn_ballot_w64(nthr != 0u)));
-          // the new thresholds back into the row-indexed vector (lane 63 is nobody's row; thresholds are never 0:
-          // entry KL-1 of a list sits behind at least one other key)
-          const u32 got = (u32)__builtin_amdgcn_ds_permute((int)((nthr ? erow : 63u) << 2), (int)nthr);
-          thrv = (lane < 32 && got != 0u) ? got : thrv;
+          PG_ST(8, __popcll(__builtin_amdgcn_ballot_w64(ins)));
           pend = pend && !win;
         }
+        // the thresholds back into the row-indexed vector, straight from the lists; bounds follow where a distance moved
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const u32 nthr = lane < nr ? lstbuf[wv][lane < RB ? lane : 0][KL - 1] : thrv;
+        const bool moved = (nthr >> 24) != (thrv >> 24);
+        thrv = nthr;
         if (__builtin_amdgcn_ballot_w64(moved)) republish_all();
         PG_T1(13, ti0);
       } else if constexpr (MODE == PG_MODE_KNN) {
@@ -526,17 +543,23 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // eps (slot positions follow queue order = ascending columns per row): register by register, but only the
     // registers that hold a candidate in some lane (wave OR of the sign words), lanes in order.
     // One copy of the loop (and of flush) for the four tiles of a super-tile.
-    auto push_signs = [&](u32 am0, u32 am1, u32 am2, u32 am3, int S, u32 tm) {   // tm: bit t = tile t is flagged
+    // scan() -> push_signs(): one sign word per tile of the super-tile - bit 16 * block + r = result register r of that
+    // row block holds a candidate (named scalars: an array selected by a run-time index ends up in scratch memory)
+    u32 am0 = 0, am1 = 0, am2 = 0, am3 = 0;
+    u32 amMask = 0;                                         // bit t = tile t is flagged
+    auto push_signs = [&](int S) {
+      u32 tm = amMask;
       while (tm) {
         const int t = __builtin_ctz(tm);
         tm &= tm - 1u;
-        u32 a = t == 0 ? am0 : (t == 1 ? am1 : (t == 2 ? am2 : am3));
-        const u32 ebase = ((4u * (u32)(lane >> 5)) << SH) | (u32)((S * 4 + t) * 32 + (lane & 31));
+        u32 a = t == 1 ? am1 : (t == 2 ? am2 : (t == 3 ? am3 : am0));
+        const u32 ebase = ((u32)(4 * (lane >> 5)) << SH) | (u32)((S * 4 + t) * 32 + (lane & 31));
         if constexpr (MODE == PG_MODE_KNN) {
           u64 mb = __builtin_amdgcn_ballot_w64(a != 0u);
           while (mb) {
-            const u32 b = (u32)__builtin_ctz(a | 0x10000u); // register; its row: (b & 3) + 8 * (b >> 2) = b + (b & 12)
-            if (a != 0u) cq[qn + mask_rank(mb)] = ebase + ((b + (b & 12u)) << SH);
+            // bit b: row block b >> 4, register b & 15; the register's row in its block: (r & 3) + 8 * (r >> 2) = r + (r & 12)
+            const u32 b = (u32)__builtin_ctz(a | 0x80000000u);
+            if (a != 0u) cq[qn + mask_rank(mb)] = ebase + ((b + (b & 12u) + (b & 16u)) << SH);
             const int n = (int)__popcll(mb);
             PG_ST(6, n);
             PG_ST(20, 1);
@@ -574,77 +597,117 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // v_readfirstlane (where it takes a loop for divergent) or v_readlane (an SGPR spill reload): that was a
     // wrong-address fault.  So the base is copied by an s_mov INSIDE the statement (a scalar write has no such
     // hazard), all four loads are ONE statement, and the moving part of the address is the vector offset.
-#define PG_RING_LOAD(c, voff)                                                                    \
+#ifndef PG_EXP_HALFLOAD
+#define PG_EXP_LD23 "global_load_dwordx4 %2, %5, %4 offset:2048\n\tglobal_load_dwordx4 %3, %5, %4 offset:3072"
+#define PG_EXP_VMCNT "4"
+#else   // experiment: only two of the four fragment loads (half the vector-memory traffic; wrong results, timing only)
+#define PG_EXP_LD23 "s_nop 0"
+#define PG_EXP_VMCNT "2"
+#endif
+#define PG_RING_LOAD(c, x0, x1, x2, x3, voff)                                                    \
   asm volatile("s_mov_b64 %4, %6\n\t"                                                            \
                "global_load_dwordx4 %0, %5, %4 offset:0\n\t"                                     \
                "global_load_dwordx4 %1, %5, %4 offset:1024\n\t"                                  \
-               "global_load_dwordx4 %2, %5, %4 offset:2048\n\t"                                  \
-               "global_load_dwordx4 %3, %5, %4 offset:3072"                                      \
-               : c(r0), c(r1), c(r2), c(r3), "=&s"(ringBase) : "v"(voff), "s"(colsig) : "memory")
-    u32 am0 = 0, am1 = 0, am2 = 0, am3 = 0, amTiles = 0;    // scan() -> push_signs(): sign words of the flagged tiles
-    // THE HOT LOOP: super-tiles S, S+1, .. below `stop` in the MFMA form while none holds a candidate - four MFMAs on
-    // the ring, the OR of each result, one sign test, the ring refilled with the next super-tile's fragments.  A tight
-    // loop of its own: nothing of the slow paths' state lives in registers across it, no spill code inside.
-    // Returns 0: S reached `stop`;  1: super-tile S holds candidates, their sign words are in am0..3 / amTiles;
+               PG_EXP_LD23                                                                       \
+               : c(x0), c(x1), c(x2), c(x3), "=&s"(ringBase) : "v"(voff), "s"(colsig) : "memory")
+    // THE HOT LOOP: super-tiles S, S+1, .. below `stop` in the MFMA form while none holds a candidate - per tile and
+    // row block an MFMA on the ring, the OR of its result; one sign test per super-tile; the ring refilled with the
+    // super-tile after next.  A tight loop of its own: nothing of the slow paths' state lives in registers across it, no
+    // spill code inside.
+    // Returns 0: S reached `stop`;  1: super-tile S holds candidates, their sign words are in am[] / amMask;
     // 2: most lane slots of S hold a candidate - the signature is not selective here, the dense form takes over.
-    auto scan = [&](int &S, int stop) -> int {
+    auto scan = [&](int &S, int stop, int last) -> int {   // last = send - 1: nothing is fetched beyond it
       u32 voff = ulane * 16u + (u32)S * 4096u;
-      pg_v4i r0, r1, r2, r3;
+      // TWO rings: while one super-tile is evaluated the next one's fragments are already on their way - loads are
+      // issued a whole iteration before they are needed; the loop is unrolled by two so the rings swap roles instead
+      // of being copied.  vmcnt(4): the older ring has landed, the younger one (four loads) may still be out.
+      pg_v4i r0, r1, r2, r3, q0, q1, q2, q3;
       unsigned long long ringBase;                          // (scratch SGPR pair of the load statement)
-      PG_RING_LOAD("=&v", voff);
-      int a0, a1, a2, a3;
+      int av0 = 0, av1 = 0, av2 = 0, av3 = 0, av4 = 0, av5 = 0, av6 = 0, av7 = 0;   // OR of MFMA m = tile * R + block
       bool found;
-      for (;;) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");   // ring_wait
-#if defined(PG_MM_STATS) && defined(PG_MM_CHECK_RING)
-        {   // debug: the ring against ordinary loads of the same fragments
-          const pg_v4i *cp = colsig + (long long)S * 256;
-          const pg_v4i c0 = cp[ulane], c1 = cp[ulane + 64u], c2 = cp[ulane + 128u], c3 = cp[ulane + 192u];
-          const bool b0 = c0[0] != r0[0] || c0[1] != r0[1] || c0[2] != r0[2] || c0[3] != r0[3];
-          const bool b1 = c1[0] != r1[0] || c1[1] != r1[1] || c1[2] != r1[2] || c1[3] != r1[3];
-          const bool b2 = c2[0] != r2[0] || c2[1] != r2[1] || c2[2] != r2[2] || c2[3] != r2[3];
-          const bool b3 = c3[0] != r3[0] || c3[1] != r3[1] || c3[2] != r3[2] || c3[3] != r3[3];
-          if (__builtin_amdgcn_ballot_w64(b0)) PG_ST(22, 1);
-          if (__builtin_amdgcn_ballot_w64(b1 || b2 || b3)) PG_ST(23, 1);
-        }
-#endif
-        pg_v16i d0 = pg_mfma_fp4(A0, r0);
-        pg_v16i d1 = pg_mfma_fp4(A0, r1);
-        __builtin_amdgcn_sched_barrier(0);                  // (two MFMAs in the pipe before the first OR)
-        a0 = pg_or16(d0);
-        __builtin_amdgcn_sched_barrier(0);                  // two result sets in turn, not four
-        d0 = pg_mfma_fp4(A0, r2);
-        a1 = pg_or16(d1);
-        __builtin_amdgcn_sched_barrier(0);
-        d1 = pg_mfma_fp4(A0, r3);
-        a2 = pg_or16(d0);
-        a3 = pg_or16(d1);
-        PG_ST(0, 1);
-        PG_ST(9, resweep);
-        found = __builtin_amdgcn_ballot_w64((a0 | a1 | a2 | a3) < 0) != 0;
-        if (found || S + 1 >= stop) break;                  // (the loop's one exit)
-        ++S;
-        voff += 4096u;
-        PG_RING_LOAD("+&v", voff);                          // the next super-tile's fragments (four loads in flight)
+      // two result sets in turn (the 128-VGPR budget), two MFMAs in the pipe before the first OR
+#define PG_SB __builtin_amdgcn_sched_barrier(0)
+#define PG_RING_STEP(x0, x1, x2, x3)                                                               \
+      {                                                                                            \
+        pg_v16i d0, d1;                                                                            \
+        if constexpr (R == 1) {                                                                    \
+          d0 = pg_mfma_fp4(A0, x0); d1 = pg_mfma_fp4(A0, x1); PG_SB;                               \
+          av0 = pg_or16(d0); PG_SB; d0 = pg_mfma_fp4(A0, x2);                                      \
+          av1 = pg_or16(d1); PG_SB; d1 = pg_mfma_fp4(A0, x3);                                      \
+          av2 = pg_or16(d0);                                                                       \
+          av3 = pg_or16(d1);                                                                       \
+          found = __builtin_amdgcn_ballot_w64((av0 | av1 | av2 | av3) < 0) != 0;                   \
+        } else {                                                                                   \
+          d0 = pg_mfma_fp4(A0, x0); d1 = pg_mfma_fp4(A1, x0); PG_SB;                               \
+          av0 = pg_or16(d0); PG_SB; d0 = pg_mfma_fp4(A0, x1);                                      \
+          av1 = pg_or16(d1); PG_SB; d1 = pg_mfma_fp4(A1, x1);                                      \
+          av2 = pg_or16(d0); PG_SB; d0 = pg_mfma_fp4(A0, x2);                                      \
+          av3 = pg_or16(d1); PG_SB; d1 = pg_mfma_fp4(A1, x2);                                      \
+          av4 = pg_or16(d0); PG_SB; d0 = pg_mfma_fp4(A0, x3);                                      \
+          av5 = pg_or16(d1); PG_SB; d1 = pg_mfma_fp4(A1, x3);                                      \
+          av6 = pg_or16(d0);                                                                       \
+          av7 = pg_or16(d1);                                                                       \
+          found = __builtin_amdgcn_ballot_w64((av0 | av1 | av2 | av3 | av4 | av5 | av6 | av7) < 0) != 0; \
+        }                                                                                          \
+        PG_ST(0, 1);                                                                               \
+        PG_ST(9, resweep);                                                                         \
       }
+      // (no branch around a load statement: where two paths with different statements meet, the compiler copies
+      //  ring registers - while their loads are still out.  So the prefetch is unconditional; at the last super-tile
+      //  of the sweep it fetches that super-tile again.)
+      PG_RING_LOAD("=&v", r0, r1, r2, r3, voff);
+      bool inQ = false;                                     // the super-tile the loop stopped at sits in q0..3
+      for (;;) {
+        voff += (S < last && !PG_EXP_SAMETILE) ? 4096u : 0u;
+        PG_RING_LOAD("=&v", q0, q1, q2, q3, voff);
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+        PG_RING_STEP(r0, r1, r2, r3);
+        if (found || S + 1 >= stop) break;
+        ++S;
+        voff += (S < last && !PG_EXP_SAMETILE) ? 4096u : 0u;
+        PG_RING_LOAD("=&v", r0, r1, r2, r3, voff);
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
+        PG_RING_STEP(q0, q1, q2, q3);
+        if (found || S + 1 >= stop) { inQ = true; break; }
+        ++S;
+      }
+      // whatever is still on its way lands before anything else touches the registers (RULE); the prefetched
+      // super-tile is given up (the next scan() fetches it again)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : : "memory");
+      if (inQ) { r0 = q0; r1 = q1; r2 = q2; r3 = q3; }
+#undef PG_RING_STEP
+#undef PG_SB
       if (!found) {
         ++S;
         return 0;
       }
       PG_ST(1, 1);
-      const u64 m0 = __builtin_amdgcn_ballot_w64(a0 < 0), m1 = __builtin_amdgcn_ballot_w64(a1 < 0);
-      const u64 m2 = __builtin_amdgcn_ballot_w64(a2 < 0), m3 = __builtin_amdgcn_ballot_w64(a3 < 0);
-      const int nslots = (int)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+      // MFMAs with a candidate; the lane slots (column x 16-row half) that hold one
+      int nslots = 0;
+      u32 mask = 0;                                         // bit m = MFMA m (tile m / R, row block m % R)
+#define PG_FLAG(m, v) { const u64 mm = __builtin_amdgcn_ballot_w64((v) < 0); nslots += (int)__popcll(mm); mask |= mm ? (1u << (m)) : 0u; }
+      PG_FLAG(0, av0) PG_FLAG(1, av1) PG_FLAG(2, av2) PG_FLAG(3, av3)
+      if constexpr (R == 2) { PG_FLAG(4, av4) PG_FLAG(5, av5) PG_FLAG(6, av6) PG_FLAG(7, av7) }
+#undef PG_FLAG
 #ifdef PG_MM_KNOBS
-      if (nslots >= K().mmDenseL1) return 2;                // (tuning builds: PG_MM_L1 at run time)
+      if (nslots >= R * K().mmDenseL1) return 2;            // (tuning builds: PG_MM_L1 at run time)
 #else
-      if (nslots >= PG_MM_DENSE_L1) return 2;
+      if (nslots >= R * PG_MM_DENSE_L1) return 2;
 #endif
-      am0 = m0 ? signs16(pg_mfma_fp4(A0, r0)) : 0u;         // the flagged tiles again, from the ring
-      am1 = m1 ? signs16(pg_mfma_fp4(A0, r1)) : 0u;
-      am2 = m2 ? signs16(pg_mfma_fp4(A0, r2)) : 0u;
-      am3 = m3 ? signs16(pg_mfma_fp4(A0, r3)) : 0u;
-      amTiles = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
+      // the flagged MFMAs again, from the ring: the sign word of every tile
+      auto tile_signs = [&](int t, const pg_v4i &x) -> u32 {
+        u32 a = 0;
+        if constexpr (R == 1) {
+          if ((mask >> t) & 1u) a = signs16(pg_mfma_fp4(A0, x));
+        } else {
+          if ((mask >> (2 * t + 1)) & 1u) a = signs16(pg_mfma_fp4(A1, x)) << 16;
+          if ((mask >> (2 * t)) & 1u) a |= signs16(pg_mfma_fp4(A0, x));
+        }
+        return a;
+      };
+      am0 = tile_signs(0, r0); am1 = tile_signs(1, r1); am2 = tile_signs(2, r2); am3 = tile_signs(3, r3);
+      if constexpr (R == 1) amMask = mask;
+      else amMask = ((mask & 3u) ? 1u : 0u) | ((mask & 12u) ? 2u : 0u) | ((mask & 48u) ? 4u : 0u) | ((mask & 192u) ? 8u : 0u);
       return 1;
     };
 
@@ -676,7 +739,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     };
     u32 seqv;                                               // lane r: sequence index of pass row r (rows past nr: the last row's)
     {
-      const long long i = pr0 + ((lane & 31) < nr ? (lane & 31) : nr - 1);
+      const long long i = pr0 + ((lane & (RB - 1)) < nr ? (lane & (RB - 1)) : nr - 1);
       seqv = (u32)(ka.row0 + (ka.rowList ? ka.rowList[i] : i));
     }
     auto load_row_fold = [&](const DenseArgs &da, u32 (&f)[B], int rr) {
@@ -703,7 +766,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     auto neg_bounds = [&]() -> u32 {
       if constexpr (kEps) return lane < nr ? 0u - p.hi1 : 0u;
       const u32 t = thrv >> 24;                             // open lists read 255
-      const bool live = lane < nr && (!resweep || ((failed >> (lane & 31)) & 1u));
+      const bool live = lane < nr && (!resweep || ((failed >> lane) & 1ull));
       return live ? 0u - ((t < capv ? t : capv) + resweep) : 0u;
     };
     auto load_rec = [&](uint4 (&dst)[Q], long long col) {
@@ -754,54 +817,64 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       const u32 nbv = neg_bounds();
 #pragma unroll
       for (int b = 0; b < CF; ++b) load_col_fold(da, cfn[b], nxt + b * 64 + lane);
-      u32 acc[CF];                                          // after np rows: bit np-1-r = row r is inside its bound
+      // per row block (32 rows share a hit word): after the block's npb rows, bit npb-1-r = its row r is inside its bound
+      u32 acc[R * CF];
+      int npb[R];
+      u32 all = 0;
 #pragma unroll
-      for (int b = 0; b < CF; ++b) acc[b] = 0;
-      u32 rf[GR][B], rn[GR][B];
+      for (int blk = 0; blk < R; ++blk) {
+        const int nrb = nr - 32 * blk < 0 ? 0 : (nr - 32 * blk > 32 ? 32 : nr - 32 * blk);   // rows of this block
+        const int np = (nrb + GR - 1) / GR * GR;
+        npb[blk] = np;
 #pragma unroll
-      for (int u = 0; u < GR; ++u) load_row_fold(da, rf[u], u);
-      const int np = (nr + GR - 1) / GR * GR;
-      for (int r0 = 0; r0 < np; r0 += GR) {
+        for (int b = 0; b < CF; ++b) acc[blk * CF + b] = 0;
+        u32 rf[GR][B], rn[GR][B];
 #pragma unroll
-        for (int u = 0; u < GR; ++u) load_row_fold(da, rn[u], r0 + GR + u);
-        u32 t[GR][CF];
+        for (int u = 0; u < GR; ++u) load_row_fold(da, rf[u], 32 * blk + u);
+        for (int r0 = 0; r0 < np; r0 += GR) {
 #pragma unroll
-        for (int u = 0; u < GR; ++u)
+          for (int u = 0; u < GR; ++u) load_row_fold(da, rn[u], 32 * blk + r0 + GR + u);
+          u32 t[GR][CF];
 #pragma unroll
-          for (int b = 0; b < CF; ++b) {
-            t[u][b] = rf[u][0] ^ cf[b][0];
+          for (int u = 0; u < GR; ++u)
 #pragma unroll
-            for (int pl = 1; pl < B; ++pl) t[u][b] = __builtin_amdgcn_bitop3_b32(rf[u][pl], cf[b][pl], t[u][b], PG_BITOP_XOR_OR);
+            for (int b = 0; b < CF; ++b) {
+              t[u][b] = rf[u][0] ^ cf[b][0];
+#pragma unroll
+              for (int pl = 1; pl < B; ++pl) t[u][b] = __builtin_amdgcn_bitop3_b32(rf[u][pl], cf[b][pl], t[u][b], PG_BITOP_XOR_OR);
+            }
+#pragma unroll
+          for (int u = 0; u < GR; ++u) {
+            const u32 nb = (u32)__builtin_amdgcn_readlane((int)nbv, 32 * blk + r0 + u);
+#pragma unroll
+            for (int b = 0; b < CF; ++b)                    // lb - bound: negative = may be within the bound
+              acc[blk * CF + b] = __builtin_amdgcn_alignbit(acc[blk * CF + b], (u32)__builtin_popcount(t[u][b]) + nb, 31);
           }
 #pragma unroll
-        for (int u = 0; u < GR; ++u) {
-          const u32 nb = (u32)__builtin_amdgcn_readlane((int)nbv, r0 + u);
+          for (int u = 0; u < GR; ++u)
 #pragma unroll
-          for (int b = 0; b < CF; ++b)                      // lb - bound: negative = may be within the bound
-            acc[b] = __builtin_amdgcn_alignbit(acc[b], (u32)__builtin_popcount(t[u][b]) + nb, 31);
+            for (int pl = 0; pl < B; ++pl) rf[u][pl] = rn[u][pl];
         }
 #pragma unroll
-        for (int u = 0; u < GR; ++u)
-#pragma unroll
-          for (int pl = 0; pl < B; ++pl) rf[u][pl] = rn[u][pl];
+        for (int b = 0; b < CF; ++b) all |= acc[blk * CF + b];
       }
       int ncand = 0;
-      u32 all = acc[0];
-#pragma unroll
-      for (int b = 1; b < CF; ++b) all |= acc[b];
       // three lanes of four with a hit: the bound is not selective here (bounds still loose, eps graphs of dense
       // data, unrelated sequences).  Nothing is queued - the caller takes the tile again in the exact form
       if (__popcll(__builtin_amdgcn_ballot_w64(all != 0)) >= 48) return -1;
       if constexpr (MODE == PG_MODE_KNN) {
-        // the hits, lane-parallel: per slice every lane that holds any queues its lowest one, until none is left
+        // the hits, lane-parallel: per hit word every lane that holds any queues its lowest one, until none is left
         // (one or two turns as a rule; the order of a row's candidates does not matter to its list)
+#pragma unroll
+        for (int blk = 0; blk < R; ++blk)
 #pragma nounroll
         for (int b = 0; b < CF; ++b) {
-          u32 a = b == 0 ? acc[0] : (b == 1 ? acc[1] : (b == 2 ? acc[2] : acc[3]));
+          u32 a = b == 1 ? acc[blk * CF + 1] : (b == 2 ? acc[blk * CF + 2] : (b == 3 ? acc[blk * CF + 3] : acc[blk * CF]));
+          const u32 rowTop = (u32)(32 * blk + npb[blk] - 1);
           u64 mb = __builtin_amdgcn_ballot_w64(a != 0);
           while (mb) {
             const u32 j = (u32)__builtin_ctz(a | 0x80000000u);
-            if (a != 0) cq[qn + mask_rank(mb)] = ((u32)(np - 1) - j) << SH | ((u32)colbase + b * 64 + lane);
+            if (a != 0) cq[qn + mask_rank(mb)] = (rowTop - j) << SH | ((u32)colbase + b * 64 + lane);
             const int n = (int)__popcll(mb);
             qn += n;
             ncand += n;
@@ -812,6 +885,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         }
       } else {
         // the hits, row by row (a row's columns stay in ascending order in the queue: slices, then lanes)
+        const int np = npb[0];
         u32 rowsHit = (u32)__builtin_amdgcn_readlane((int)wave_or_to63(all), 63);
         while (rowsHit) {
           const int j = __builtin_ctz(rowsHit);
@@ -850,11 +924,11 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         const int sw2 = (nst + 7) >> 3;
         const bool at2 = snext >= sw2;
         nextCk = at2 ? kNoCk : sw2;
-        const bool mine = lane < nr && !((failed >> (lane & 31)) & 1);
+        const bool mine = lane < nr && !((failed >> lane) & 1ull);
         u32 dref = thrv >> 24;                             // open lists read 255
-        if (!at2) dref = mine ? lstbuf[wv][lane & 31][lfirst] >> 24 : 0u;
+        if (!at2) dref = mine ? lstbuf[wv][lane < RB ? lane : 0][lfirst] >> 24 : 0u;
         const bool late = mine && dref >= G0;
-        const u32 now = (u32)__builtin_amdgcn_ballot_w64(late);   // rows < 32
+        const u64 now = __builtin_amdgcn_ballot_w64(late);
         if (now) {
           failed |= now;
           sredo = snext;
@@ -949,13 +1023,13 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         const int Sin = S;
         PG_ST(18, 1);
         PG_T0(ts0);
-        const int rc = scan(S, send < nextCk ? send : nextCk);
+        const int rc = scan(S, send < nextCk ? send : nextCk, send - 1);
         PG_T1(16, ts0);
         if (S != Sin) drun = 0;                             // a clean stretch ends a series of dense runs
         if (rc == 0) continue;
         if (rc == 1) {                                      // candidates queued, the MFMA form goes on
           PG_T0(tq0);
-          push_signs(am0, am1, am2, am3, S, amTiles);
+          push_signs(S);
           PG_T1(17, tq0);
           ++S;
           drun = 0;
@@ -974,7 +1048,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         // phase 1: the rows that lost their cap see super-tiles [0, sredo) again; the others are frozen
         resweep = 1;
         nextCk = kNoCk;
-        set_all_bounds((lane < nr && ((failed >> (lane & 31)) & 1)) ? (thrv >> 24) + 1u : 0u);
+        set_all_bounds((lane < nr && ((failed >> lane) & 1ull)) ? (thrv >> 24) + 1u : 0u);
         send = sredo;
       } else {
         break;

@@ -61,10 +61,10 @@ int PG_CAT(pg_launch_nsq_g, PG_G)(int mode, int bits, const NsqParams &p, int gr
   return bits == 5 ? launch_nsq<5, PG_MODE_KNN>(p, grid, s) : launch_nsq<8, PG_MODE_KNN>(p, grid, s);
 }
 
-template <int B, int MODE, int KL = 64>
+template <int B, int MODE, int KL = 64, int R = 1>
 static int launch_mm(const NsqParams &p, int grid, hipStream_t s) {
   if constexpr (Cols<B>::kBuilt) {
-    pg_mm_kernel<HammingMetric<PG_G, B>, MODE, KL><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+    pg_mm_kernel<HammingMetric<PG_G, B>, MODE, KL, R><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
     return (int)hipGetLastError();
   } else {
     return (int)hipErrorInvalidValue;
@@ -78,6 +78,8 @@ int PG_CAT(pg_launch_mm_g, PG_G)(int mode, int bits, const NsqParams &p, int gri
   // kNN with short lists (k + 1 <= PG_MM_KL, first round only): the lane-per-candidate insertion instance
   if (mode == PG_MODE_KNN_SHORT)
     return bits == 5 ? launch_mm<5, PG_MODE_KNN, PG_MM_KL>(p, grid, s) : launch_mm<8, PG_MODE_KNN, PG_MM_KL>(p, grid, s);
+  if (mode == PG_MODE_KNN_SHORT2)   // ... and two row blocks per pass
+    return bits == 5 ? launch_mm<5, PG_MODE_KNN, PG_MM_KL, 2>(p, grid, s) : launch_mm<8, PG_MODE_KNN, PG_MM_KL, 2>(p, grid, s);
   return bits == 5 ? launch_mm<5, PG_MODE_KNN>(p, grid, s) : launch_mm<8, PG_MODE_KNN>(p, grid, s);
 }
 
