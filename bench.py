@@ -210,7 +210,8 @@ def run_workload(name, G, rank, dev, use_dist, backend, steps, warmup, want_pcie
             sargs = (_native._ptr(planes.buf), planes.npad, planes.n, planes.g * 32, planes.bits, _native.CMP_LE,
                      float(wl["eps"]), cap, _native._ptr(slot_idx), _native._ptr(slot_w), _native._ptr(counts),
                      _native._ptr(counts_lo))
-            _native._check(L_.pg_eps_slots_sym(*sargs, _native._stream()), "pg_eps_slots_sym")
+            _native._check(L_.pg_eps_slots_sym(*sargs, _native._ptr(_native.workspace(rows_local, dev)), _native._stream()),
+                           "pg_eps_slots_sym")
             e1.record()
             total = counts + counts_lo
             indptr = torch.empty(rows_local + 1, dtype=torch.int64, device=dev)

@@ -11,12 +11,21 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (torch tensors are the
- *     storage container); the library never allocates, frees or synchronises;
+ *     storage container); the library never allocates or frees device memory and never
+ *     synchronises.  The all-pairs calls (pg_eps_slots[_sym], pg_eps_fill_rows,
+ *     pg_knn_hamming[_round]) take a caller-owned `workspace` of pg_workspace_bytes(nrows)
+ *     bytes: launch-private device state (the pass counter of the engine's persistent waves),
+ *     initialised by the call on `stream`; ONE workspace per launch in flight - a workspace
+ *     may be reused once the launch that got it has completed, or by later launches on the
+ *     same stream;
  *   - every launch goes to the caller-supplied `stream` (a hipStream_t passed as void*,
- *     NULL = the null stream); calls are re-entrant per stream;
+ *     NULL = the null stream) on the CURRENT HIP device of the calling thread; calls are
+ *     re-entrant per stream and per device;
  *   - return value: 0 = ok, >0 = a hipError_t from the launch, <0 = PG_E_* below;
  *     `pg_last_error()` returns a thread-local human readable message;
- *   - no exceptions cross the boundary, no hidden global state.
+ *   - no exceptions cross the boundary.  Process-wide state, all of it host side: the
+ *     thread-local error string, the per-device cache of the compute-unit count and of the
+ *     engine instances' occupancy, and the run-time binding of RCCL (pg_comm_*).
  *
  * Token storage: bit-sliced records in chunk-major order ("planes").  A sequence of L tokens
  * of `bits` bits each is G = ceil(L/32) groups of `bits` bit-plane dwords: dword p*G+g (plane
@@ -45,7 +54,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 2   /* 2: plane buffers carry the signature and fold sections */
+#define PG_ABI_VERSION 3   /* 2: plane buffers carry the signature and fold sections; 3: caller-owned workspace */
 
 /* library error codes (negative return values) */
 #define PG_E_BADARG   (-1)   /* NULL pointer, negative size, k out of range ...        */
@@ -82,6 +91,8 @@ int         pg_ngroups(int l);
 int         pg_nchunks(int l, int bits);
 /* bytes of a plane buffer for n sequences of l tokens: chunk arrays + signature section */
 int64_t     pg_planes_bytes(int64_t n, int l, int bits);
+/* bytes of the launch-private `workspace` of an all-pairs call over nrows rows (see Conventions) */
+int64_t     pg_workspace_bytes(int64_t nrows);
 
 /*
  * pg_pack_planes — row-major tokens -> plane layout.
@@ -127,7 +138,7 @@ int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad,
 int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
                  const void *col_planes, int64_t col_npad, int64_t ncols,
                  int l, int bits, int cmp, double eps, int cap,
-                 int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts, void *stream);
+                 int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts, void *workspace, void *stream);
 
 /*
  * Square self-graph variant of pg_eps_slots / pg_eps_compact: rows [0,n) against the same n sequences.
@@ -141,7 +152,8 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
  * The result is identical to pg_eps_slots + pg_eps_compact on the same input.
  */
 int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bits, int cmp, double eps, int cap,
-                     int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts_up, uint32_t *counts_lo, void *stream);
+                     int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts_up, uint32_t *counts_lo, void *workspace,
+                     void *stream);
 int pg_eps_compact_sym(const void *planes, int64_t npad, int64_t n, int l, int bits, int cmp, double eps, int cap,
                        const int32_t *slot_idx, const uint8_t *slot_w, const uint32_t *counts_up,
                        const uint32_t *counts_lo, const int64_t *indptr, int32_t *indices, uint8_t *weights,
@@ -180,7 +192,8 @@ int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64
  */
 int pg_eps_fill_rows(const void *row_planes, int64_t row_npad, int64_t row0, const int64_t *row_list, int64_t n_list,
                      const void *col_planes, int64_t col_npad, int64_t ncols, int l, int bits, int cmp, double eps,
-                     const int64_t *indptr, int32_t *indices, uint8_t *weights, uint32_t *scratch_counts, void *stream);
+                     const int64_t *indptr, int32_t *indices, uint8_t *weights, uint32_t *scratch_counts, void *workspace,
+                     void *stream);
 
 /*
  * pg_knn_hamming — k nearest neighbours under the canonical (distance, index) order.
@@ -193,7 +206,7 @@ int pg_eps_fill_rows(const void *row_planes, int64_t row_npad, int64_t row0, con
 int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
                    const void *col_planes, int64_t col_npad, int64_t ncols,
                    int l, int bits, int k, int32_t *idx_out, uint8_t *dist_out,
-                   void *stream);
+                   void *workspace, void *stream);
 
 /*
  * pg_knn_hamming_round — kNN beyond 63 neighbours, 63/64 ranks per all-pairs round.
@@ -206,7 +219,7 @@ int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64
 int pg_knn_hamming_round(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows,
                          const void *col_planes, int64_t col_npad, int64_t ncols, int l, int bits,
                          int k, int first_round, const uint32_t *floor_keys, uint32_t *last_keys,
-                         int32_t *idx_out, uint8_t *dist_out, void *stream);
+                         int32_t *idx_out, uint8_t *dist_out, void *workspace, void *stream);
 
 /*
  * pg_index_flags — the fused 1xN pass of `Prograph.indexing` (prograph/prograph.py:

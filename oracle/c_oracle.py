@@ -19,6 +19,8 @@ def lib():
     if _lib is None:
         if not os.path.exists(_SO):
             build()
+        # a bounded team: the GPU boxes show hundreds of CPUs but grant a share of them
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(32, os.cpu_count() or 1)))
         _lib = ctypes.CDLL(_SO)
     return _lib
 
@@ -34,27 +36,29 @@ def hamming(X, Y):
     return out
 
 
-def eps_csr(T, cmp, eps, row0=0, nrows=None):
+def eps_csr(T, cmp, eps, row0=0, nrows=None, fast=False):
+    """`fast`: the vectorised leg (orc_eps_fast, pinned to the scalar one by tests/test_oracle.py) for full-size checks."""
     T = np.ascontiguousarray(T, dtype=np.uint8)
     n, l = T.shape
     nrows = n - row0 if nrows is None else nrows
     counts = np.zeros(nrows, dtype=np.int64)
     args = (_p(T), ctypes.c_int64(n), ctypes.c_int(l), ctypes.c_int64(row0), ctypes.c_int64(nrows), ctypes.c_int(cmp),
             ctypes.c_double(eps))
-    lib().orc_eps(*args, _p(counts), None, None, None)
+    f = lib().orc_eps_fast if fast else lib().orc_eps
+    f(*args, _p(counts), None, None, None)
     indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     idx = np.empty(max(int(indptr[-1]), 1), dtype=np.int32); w = np.empty(max(int(indptr[-1]), 1), dtype=np.uint8)
-    lib().orc_eps(*args, _p(counts), _p(indptr), _p(idx), _p(w))
+    f(*args, _p(counts), _p(indptr), _p(idx), _p(w))
     return indptr, idx[:indptr[-1]], w[:indptr[-1]]
 
 
-def knn(T, k, row0=0, nrows=None):
+def knn(T, k, row0=0, nrows=None, fast=False):
     T = np.ascontiguousarray(T, dtype=np.uint8)
     n, l = T.shape
     nrows = n - row0 if nrows is None else nrows
     idx = np.empty((nrows, k), dtype=np.int32); d = np.empty((nrows, k), dtype=np.uint8)
-    lib().orc_knn(_p(T), ctypes.c_int64(n), ctypes.c_int(l), ctypes.c_int64(row0), ctypes.c_int64(nrows), ctypes.c_int(k),
-                  _p(idx), _p(d))
+    f = lib().orc_knn_fast if fast else lib().orc_knn
+    f(_p(T), ctypes.c_int64(n), ctypes.c_int(l), ctypes.c_int64(row0), ctypes.c_int64(nrows), ctypes.c_int(k), _p(idx), _p(d))
     return idx, d
 
 

@@ -77,6 +77,85 @@ void orc_knn(const uint8_t *T, int64_t n, int l, int64_t row0, int64_t nrows, in
   }
 }
 
+/* ---------------------------------------------------------------------------------------
+ * FAST LEG of orc_eps / orc_knn for full-size checks (N = 200 000: 4e10 pairs).  The same definitions -
+ * d = number of differing token bytes; (comp(d, eps) & d > 0), columns ascending; the k + 1 smallest
+ * (d, column) keys, rank 0 dropped - with the byte compare done 32 bytes at a time (AVX2 vpcmpeqb +
+ * movemask + popcount; plain 8-byte words where AVX2 is missing).  Pinned: tests/test_oracle.py checks it
+ * against the scalar functions above on ragged lengths.
+ * ------------------------------------------------------------------------------------- */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2,popcnt"))) static int ham_avx2(const uint8_t *a, const uint8_t *b, int l) {
+  int eq = 0, j = 0;
+  for (; j + 32 <= l; j += 32) {
+    const __m256i x = _mm256_loadu_si256((const __m256i *)(a + j)), y = _mm256_loadu_si256((const __m256i *)(b + j));
+    eq += __builtin_popcount((unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, y)));
+  }
+  int d = j - eq;
+  for (; j < l; ++j) d += a[j] != b[j];
+  return d;
+}
+#endif
+static int ham_words(const uint8_t *a, const uint8_t *b, int l) {
+  int d = 0, j = 0;
+  for (; j + 8 <= l; j += 8) {
+    uint64_t x, y;
+    memcpy(&x, a + j, 8); memcpy(&y, b + j, 8);
+    x ^= y;
+    x |= x >> 4; x |= x >> 2; x |= x >> 1;                /* bit 0 of every byte: the byte differs */
+    d += __builtin_popcountll(x & 0x0101010101010101ULL);
+  }
+  for (; j < l; ++j) d += a[j] != b[j];
+  return d;
+}
+typedef int (*ham_fn)(const uint8_t *, const uint8_t *, int);
+static ham_fn pick_ham(void) {
+#if defined(__x86_64__)
+  if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt")) return ham_avx2;
+#endif
+  return ham_words;
+}
+
+void orc_eps_fast(const uint8_t *T, int64_t n, int l, int64_t row0, int64_t nrows, int cmp, double eps,
+                  int64_t *counts, const int64_t *indptr, int32_t *indices, uint8_t *weights) {
+  const ham_fn hf = pick_ham();
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t r = 0; r < nrows; ++r) {
+    const uint8_t *a = T + (row0 + r) * l;
+    int64_t k = 0, base = indices ? indptr[r] : 0;
+    for (int64_t c = 0; c < n; ++c) {
+      const int d = hf(a, T + c * l, l);
+      if (d > 0 && cmp_ok(cmp, (double)d, eps)) {
+        if (indices) { indices[base + k] = (int32_t)c; weights[base + k] = (uint8_t)d; }
+        ++k;
+      }
+    }
+    if (!indices) counts[r] = k;
+  }
+}
+
+void orc_knn_fast(const uint8_t *T, int64_t n, int l, int64_t row0, int64_t nrows, int k, int32_t *idx, uint8_t *dist) {
+  const ham_fn hf = pick_ham();
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t r = 0; r < nrows; ++r) {
+    const uint8_t *a = T + (row0 + r) * l;
+    int64_t best[1026];                      /* k <= 1024 */
+    int nb = 0;
+    for (int64_t c = 0; c < n; ++c) {
+      const int64_t key = ((int64_t)hf(a, T + c * l, l) << 32) | c;
+      if (nb == k + 1 && key >= best[nb - 1]) continue;
+      int p = nb < k + 1 ? nb++ : nb - 1;
+      while (p > 0 && best[p - 1] > key) { best[p] = best[p - 1]; --p; }
+      best[p] = key;
+    }
+    for (int j = 0; j < k; ++j) {
+      if (j + 1 < nb) { idx[r * k + j] = (int32_t)(best[j + 1] & 0xffffffff); dist[r * k + j] = (uint8_t)(best[j + 1] >> 32); }
+      else { idx[r * k + j] = -1; dist[r * k + j] = 255; }
+    }
+  }
+}
+
 static inline uint64_t mix64(uint64_t z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;

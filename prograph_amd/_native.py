@@ -17,7 +17,7 @@ import torch   # must be imported before the library is loaded: see _load()
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PROGRAPH_HIP_LIB: load another build of the same ABI (kernel A/B comparisons, tools/ab.py)
 LIB_PATH = os.environ.get("PROGRAPH_HIP_LIB") or os.path.join(_HERE, "libprograph_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 BITS_5, BITS_8 = 5, 8
 CMP_LE, CMP_LT, CMP_EQ, CMP_GE, CMP_GT = 0, 1, 2, 3, 4
@@ -25,7 +25,7 @@ MAX_L, MAX_L_5BIT, MAX_K, MAX_K_ROUNDS, MAX_N_KNN, LEV_MAX_BAND = 128, 255, 63, 
 
 # every symbol include/prograph_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_planes_bytes",
+    "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_planes_bytes", "pg_workspace_bytes",
     "pg_pack_planes",
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
     "pg_eps_compact", "pg_eps_fill_rows", "pg_eps_slots_sym", "pg_eps_compact_sym", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
@@ -79,22 +79,24 @@ def _load():
         lib.pg_planes_bytes.argtypes = [_i64, _i32, _i32]
         lib.pg_scan_scratch_bytes.restype = _i64
         lib.pg_scan_scratch_bytes.argtypes = [_i64]
+        lib.pg_workspace_bytes.restype = _i64
+        lib.pg_workspace_bytes.argtypes = [_i64]
         lib.pg_device_info.argtypes = [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32]
         lib.pg_pack_planes.argtypes = [_vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _i64, _vp, _vp]
         lib.pg_hamming_dense.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i64, _i32, _vp]
         lib.pg_eps_slots.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
-                                     _vp, _vp, _vp, _vp]
+                                     _vp, _vp, _vp, _vp, _vp]
         lib.pg_exclusive_scan.argtypes = [_vp, _i64, _vp, _vp, _vp]
-        lib.pg_eps_slots_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp]
+        lib.pg_eps_slots_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_eps_compact_sym.argtypes = [_vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _i32, _vp]
         lib.pg_eps_compact.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]
         lib.pg_eps_fill_rows.argtypes = [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl,
-                                         _vp, _vp, _vp, _vp, _vp]
-        lib.pg_knn_hamming.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
+                                         _vp, _vp, _vp, _vp, _vp, _vp]
+        lib.pg_knn_hamming.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]
         lib.pg_knn_hamming_round.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp,
-                                             _vp, _vp]
+                                             _vp, _vp, _vp]
         lib.pg_index_flags.argtypes = [_vp, _i64, _i64, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
         lib.pg_compact_flags.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp]
         lib.pg_csr_row_stats.argtypes = [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -144,6 +146,13 @@ def _stream():
 
 def _ptr(t):
     return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def workspace(nrows, dev):
+    """Launch-private device state of one all-pairs call (pg_workspace_bytes): a fresh block per launch - torch's
+    caching allocator hands a freed block out again only to later work on the same stream, which is exactly the
+    reuse the ABI allows."""
+    return torch.empty(int(lib().pg_workspace_bytes(int(nrows))), dtype=torch.uint8, device=dev)
 
 
 def npad(n):
@@ -294,13 +303,13 @@ def eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
     if sym:
         args = (_ptr(rp.buf), rp.npad, rp.n, rp.g * 32, bits, cmp, float(eps), cap, _ptr(slot_idx), _ptr(slot_w),
                 _ptr(counts), _ptr(counts_lo))
-        _check(L.pg_eps_slots_sym(*args, _stream()), "pg_eps_slots_sym")
+        _check(L.pg_eps_slots_sym(*args, _ptr(workspace(nrows, dev)), _stream()), "pg_eps_slots_sym")
         total = counts + counts_lo
         over = (total > cap) | (counts_lo > 512)              # more than PG_SORT_MAX entries from below: not rank-sorted in LDS
     else:
         args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, bits, cmp, float(eps),
                 cap, _ptr(slot_idx), _ptr(slot_w), _ptr(counts))
-        _check(L.pg_eps_slots(*args, _stream()), "pg_eps_slots")
+        _check(L.pg_eps_slots(*args, _ptr(workspace(nrows, dev)), _stream()), "pg_eps_slots")
         total = counts
         over = total > cap
     _check(L.pg_exclusive_scan(_ptr(total), nrows, _ptr(indptr), _ptr(scratch), _stream()), "pg_exclusive_scan")
@@ -320,7 +329,7 @@ def eps_graph(rp, cp, cmp, eps, row0=0, nrows=None, cap=256):
             again = torch.empty(n_over, dtype=torch.int32, device=dev)
             _check(L.pg_eps_fill_rows(_ptr(rp.buf), rp.npad, row0, _ptr(rows), n_over, _ptr(cp.buf), cp.npad, cp.n,
                                       cp.g * 32, bits, cmp, float(eps), _ptr(indptr), _ptr(indices), _ptr(weights),
-                                      _ptr(again), _stream()), "pg_eps_fill_rows")
+                                      _ptr(again), _ptr(workspace(n_over, dev)), _stream()), "pg_eps_fill_rows")
     return indptr, indices, weights
 
 
@@ -328,7 +337,8 @@ def eps_slots_only(rp, cp, cmp, eps, row0, nrows, cap, slot_idx, slot_w, counts)
     """Just the N^2 launch on preallocated buffers (bench.py times this)."""
     args = (_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, _bits2(rp, cp), cmp,
             float(eps), int(cap))
-    _check(lib().pg_eps_slots(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _stream()), "pg_eps_slots")
+    _check(lib().pg_eps_slots(*args, _ptr(slot_idx), _ptr(slot_w), _ptr(counts), _ptr(workspace(nrows, counts.device)), _stream()),
+           "pg_eps_slots")
 
 
 def knn_graph_rounds(rp, cp, k, row0=0, nrows=None):
@@ -348,7 +358,8 @@ def knn_graph_rounds(rp, cp, k, row0=0, nrows=None):
         ri = torch.empty((nrows, kk), dtype=torch.int32, device=dev)
         rd = torch.empty((nrows, kk), dtype=torch.uint8, device=dev)
         _check(L.pg_knn_hamming_round(_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32, bits,
-                                      kk, 1 if first else 0, _ptr(keys_a), _ptr(keys_b), _ptr(ri), _ptr(rd), _stream()),
+                                      kk, 1 if first else 0, _ptr(keys_a), _ptr(keys_b), _ptr(ri), _ptr(rd),
+                                      _ptr(workspace(nrows, dev)), _stream()),
                "pg_knn_hamming_round")
         idx[:, done:done + kk] = ri
         dist[:, done:done + kk] = rd
@@ -370,7 +381,8 @@ def knn_graph(rp, cp, k, row0=0, nrows=None, out=None):
     else:
         idx, dist = out
     _check(lib().pg_knn_hamming(_ptr(rp.buf), rp.npad, row0, nrows, _ptr(cp.buf), cp.npad, cp.n, cp.g * 32,
-                                _bits2(rp, cp), int(k), _ptr(idx), _ptr(dist), _stream()), "pg_knn_hamming")
+                                _bits2(rp, cp), int(k), _ptr(idx), _ptr(dist), _ptr(workspace(nrows, dev)), _stream()),
+           "pg_knn_hamming")
     return idx, dist
 
 

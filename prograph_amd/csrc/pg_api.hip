@@ -32,14 +32,18 @@ static int launched(int rc, const char *where) {
 // stage-1 lower-bound filter of the engine: adaptive by default; PG_LB_FILTER=0 disables, =2 forces it on
 static int lb_filter_mode() { return getenv("PG_LB_FILTER") ? atoi(getenv("PG_LB_FILTER")) : 1; }
 
-static int g_cus = 0;
+// compute units of the CURRENT device (cached per device: a process may drive several)
+#define PG_MAX_DEVICES 64
 static int cu_count() {
-  if (g_cus > 0) return g_cus;
+  static std::atomic<int> cus[PG_MAX_DEVICES];
   int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  const bool cached = dev >= 0 && dev < PG_MAX_DEVICES;
+  if (cached && cus[dev].load(std::memory_order_relaxed) > 0) return cus[dev].load(std::memory_order_relaxed);
   hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  g_cus = prop.multiProcessorCount;
-  return g_cus;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (cached) cus[dev].store(prop.multiProcessorCount, std::memory_order_relaxed);
+  return prop.multiProcessorCount;
 }
 
 // waves per CU the all-pairs engine is sized for (PG_WAVES_PER_CU overrides; multiples of 4)
@@ -73,6 +77,9 @@ int64_t pg_npad(int64_t n) { return n <= 0 ? 256 : ((n + 255) / 256) * 256; }
 int pg_ngroups(int l) { return l <= 0 ? 1 : (l + 31) / 32; }
 int pg_nchunks(int l, int bits) { return (pg_ngroups(l) * bits + 3) / 4; }
 int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunks(l, bits) * 16 + PG_AUX_BYTES) * pg_npad(n); }
+// launch-private device state of an all-pairs call: today the pass counter of the persistent waves (one word in a
+// 64-byte line of its own); sized by the row count so that later per-row state needs no ABI change
+int64_t pg_workspace_bytes(int64_t nrows) { (void)nrows; return 256; }
 
 }  // extern "C"
 
@@ -347,13 +354,15 @@ static const occ_fn kNsqOcc[8] = {pg_occ_nsq_g1, pg_occ_nsq_g2, pg_occ_nsq_g3, p
                                   pg_occ_nsq_g5, pg_occ_nsq_g6, pg_occ_nsq_g7, pg_occ_nsq_g8};
 // resident waves per SIMD (= workgroups per CU) of an engine instance, asked once from the runtime
 static int nsq_occupancy(int groups, int mode, int bits) {
-  static int cache[8][3][2];
-  int &c = cache[groups - 1][mode][bits == 8];
-  if (c == 0) {
+  static std::atomic<int> cache[8][3][2];                  // (a property of the code object: the same on every gfx950)
+  std::atomic<int> &c = cache[groups - 1][mode][bits == 8];
+  int v = c.load(std::memory_order_relaxed);
+  if (v == 0) {
     const int n = kNsqOcc[groups - 1](mode, bits);
-    c = n < 1 ? 4 : (n > 8 ? 8 : n);
+    v = n < 1 ? 4 : (n > 8 ? 8 : n);
+    c.store(v, std::memory_order_relaxed);
   }
-  return c;
+  return v;
 }
 static const nsq_fn kNsq[8] = {pg_launch_nsq_g1, pg_launch_nsq_g2, pg_launch_nsq_g3, pg_launch_nsq_g4,
                                pg_launch_nsq_g5, pg_launch_nsq_g6, pg_launch_nsq_g7, pg_launch_nsq_g8};
@@ -562,29 +571,21 @@ static void plan_mm(int64_t nrows, NsqParams *p, int *grid, int rb = PG_MM_RB) {
   p->mmPasses = waves; p->mmGridWaves = gridWaves;
   *grid = (int)(gridWaves / PG_WG_WAVES);
 }
-// The pass counter of a launch: one of a ring of 256 device words, zeroed on the launch's stream right before
-// the kernel (concurrent launches on different streams get different words).
-static int pass_counter(NsqParams *p, hipStream_t s) {
-  static unsigned *ring = nullptr;
-  static std::atomic<unsigned> next{0};
-  if (!ring) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> g(mu);
-    if (!ring) {
-      unsigned *r = nullptr;
-      if (hipMalloc(&r, 256 * 64) != hipSuccess) return fail(PG_E_NODEV, "pass counters: hipMalloc failed");
-      ring = r;
-    }
-  }
-  unsigned *c = ring + 16 * (next.fetch_add(1) & 255u);    // one counter per 64-byte line
-  if (hipMemsetAsync(c, 0, 4, s) != hipSuccess) return fail(PG_E_NODEV, "pass counters: hipMemsetAsync failed");
+// The pass counter of a launch lives in the caller's workspace (pg_workspace_bytes): zeroed on the launch's stream
+// right before the kernel.  Launch-private by contract, so concurrent launches - other streams, other devices,
+// any number of them - never share a word (the static ring of counters this replaces did after 256 launches).
+static int pass_counter(NsqParams *p, void *workspace, hipStream_t s) {
+  if (!workspace) return fail(PG_E_BADARG, "workspace required (pg_workspace_bytes)");
+  unsigned *c = (unsigned *)workspace;
+  const hipError_t e = hipMemsetAsync(c, 0, 64, s);
+  if (e != hipSuccess) return hipfail(e, "workspace: hipMemsetAsync");
   p->mmPassCounter = c;
   return 0;
 }
 
 int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
                  int64_t col_npad, int64_t ncols, int l, int bits, int cmp, double eps, int cap, int32_t *slot_idx,
-                 uint8_t *slot_w, uint32_t *counts, void *stream) {
+                 uint8_t *slot_w, uint32_t *counts, void *workspace, void *stream) {
   NsqParams p;
   if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits)) return rc;
   if (!slot_idx || !slot_w || !counts || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
@@ -595,7 +596,7 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
   int grid = 0;
   if (use_mm_engine(nrows, l, false)) {
     plan_mm(nrows, &p, &grid);
-    if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
+    if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
     return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps)");
   }
   if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS, bits), 16.0 * pg_nchunks(l, bits))) return rc;
@@ -606,7 +607,8 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
 // the engine sweeps only columns above the row, a match (i, j) goes to the front of row i's slot
 // in column order and to the back of row j's slot through an atomic counter.
 int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bits, int cmp, double eps, int cap,
-                     int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts_up, uint32_t *counts_lo, void *stream) {
+                     int32_t *slot_idx, uint8_t *slot_w, uint32_t *counts_up, uint32_t *counts_lo, void *workspace,
+                     void *stream) {
   NsqParams p;
   if (int rc = fill_nsq(&p, planes, npad, 0, n, planes, npad, n, l, bits)) return rc;
   if (!slot_idx || !slot_w || !counts_up || !counts_lo || cap < 0 || cmp < PG_CMP_LE || cmp > PG_CMP_GT)
@@ -624,7 +626,7 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
   // N = 100k .. 200k (more rows: too few waves to balance; fewer: the per-wave column stream shows).
   if (use_mm_engine(n, l, false)) {
     plan_mm(n, &p, &grid);
-    if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
+    if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
     return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS_SYM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps sym)");
   }
   if (!getenv("PG_ROWS_PER_WAVE") && !getenv("PG_WAVES_PER_CU")) {
@@ -697,7 +699,8 @@ int pg_eps_compact(const void *row_planes, int64_t row_npad, int64_t row0, int64
 // indptr[row] - exact for any slot capacity, at engine speed however many rows overflow.
 int pg_eps_fill_rows(const void *row_planes, int64_t row_npad, int64_t row0, const int64_t *row_list, int64_t n_list,
                      const void *col_planes, int64_t col_npad, int64_t ncols, int l, int bits, int cmp, double eps,
-                     const int64_t *indptr, int32_t *indices, uint8_t *weights, uint32_t *scratch_counts, void *stream) {
+                     const int64_t *indptr, int32_t *indices, uint8_t *weights, uint32_t *scratch_counts, void *workspace,
+                     void *stream) {
   NsqParams p;
   if (!row_list || n_list <= 0) return fail(PG_E_BADARG, "pg_eps_fill_rows: bad argument");
   if (int rc = fill_nsq(&p, row_planes, row_npad, row0, n_list, col_planes, col_npad, ncols, l, bits)) return rc;
@@ -710,13 +713,13 @@ int pg_eps_fill_rows(const void *row_planes, int64_t row_npad, int64_t row0, con
   p.slotIdx = indices; p.slotW = weights; p.counts = scratch_counts;
   int grid = 0;
   plan_mm(n_list, &p, &grid);
-  if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
+  if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
   return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps fill)");
 }
 
 static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
                       int64_t col_npad, int64_t ncols, int l, int bits, int k, int first, const uint32_t *floor_keys,
-                      uint32_t *last_keys, int32_t *idx_out, uint8_t *dist_out, void *stream) {
+                      uint32_t *last_keys, int32_t *idx_out, uint8_t *dist_out, void *workspace, void *stream) {
   NsqParams p;
   if (int rc = fill_nsq(&p, row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits)) return rc;
   if (!idx_out || !dist_out) return fail(PG_E_BADARG, "pg_knn_hamming: bad argument");
@@ -742,7 +745,7 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     bool two = shortList && nrows >= 64 * slots * 6 / 10;
     if (const char *e = getenv("PG_MM_R")) two = shortList && atoi(e) == 2;
     plan_mm(nrows, &p, &grid, two ? 2 * PG_MM_RB : PG_MM_RB);
-    if (int rc = pass_counter(&p, (hipStream_t)stream)) return rc;
+    if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
     return launched(kMm[pg_ngroups(l) - 1](two ? PG_MODE_KNN_SHORT2 : (shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN), bits, p, grid,
                                            (hipStream_t)stream), "pg_mm_kernel(knn)");
   }
@@ -752,19 +755,19 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
 
 int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
                    int64_t col_npad, int64_t ncols, int l, int bits, int k, int32_t *idx_out, uint8_t *dist_out,
-                   void *stream) {
+                   void *workspace, void *stream) {
   if (k < 1 || k > PG_MAX_K) return fail(PG_E_BADARG, "pg_knn_hamming: k must be in 1..63");
   return knn_launch(row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits, k, 1, nullptr, nullptr,
-                    idx_out, dist_out, stream);
+                    idx_out, dist_out, workspace, stream);
 }
 
 int pg_knn_hamming_round(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
                          int64_t col_npad, int64_t ncols, int l, int bits, int k, int first_round,
                          const uint32_t *floor_keys, uint32_t *last_keys, int32_t *idx_out, uint8_t *dist_out,
-                         void *stream) {
+                         void *workspace, void *stream) {
   if (!last_keys || (!first_round && !floor_keys)) return fail(PG_E_BADARG, "pg_knn_hamming_round: key arrays required");
   return knn_launch(row_planes, row_npad, row0, nrows, col_planes, col_npad, ncols, l, bits, k, first_round ? 1 : 0,
-                    first_round ? nullptr : floor_keys, last_keys, idx_out, dist_out, stream);
+                    first_round ? nullptr : floor_keys, last_keys, idx_out, dist_out, workspace, stream);
 }
 
 int pg_index_flags(const void *planes, int64_t n, int64_t npad, int l, int bits, int64_t ref,
@@ -901,7 +904,8 @@ struct RcclApi {
 static RcclApi *rccl() {
   static RcclApi api;
   static int state = 0;   // 0 untried, 1 ok, -1 missing
-  if (state == 0) {
+  static std::once_flag once;
+  std::call_once(once, [&]() {
     void *h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);           // the host's copy, if it has one loaded
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -914,7 +918,7 @@ static RcclApi *rccl() {
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
     }
     state = (h && api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather) ? 1 : -1;
-  }
+  });
   return state == 1 ? &api : nullptr;
 }
 static int rcclfail(RcclApi *r, ncclResult_t e, const char *where) {

@@ -61,7 +61,9 @@ int main(int argc, char **argv) {
   // ---- kNN
   int32_t *d_idx = dmalloc<int32_t>((size_t)n * k);
   uint8_t *d_dist = dmalloc<uint8_t>((size_t)n * k);
-  PG(pg_knn_hamming(d_planes, npad, 0, n, d_planes, npad, n, l, PG_BITS_5, k, d_idx, d_dist, nullptr));
+  // launch-private workspace of the all-pairs calls (one per launch in flight; these launches are serialised on one stream)
+  void *d_ws = dmalloc<uint8_t>((size_t)pg_workspace_bytes(n));
+  PG(pg_knn_hamming(d_planes, npad, 0, n, d_planes, npad, n, l, PG_BITS_5, k, d_idx, d_dist, d_ws, nullptr));
   std::vector<int32_t> idx((size_t)n * k), ridx((size_t)n * k);
   std::vector<uint8_t> dist((size_t)n * k), rdist((size_t)n * k);
   HIP(hipMemcpy(idx.data(), d_idx, idx.size() * 4, hipMemcpyDeviceToHost));
@@ -87,10 +89,10 @@ int main(int argc, char **argv) {
   for (int sym = 0; sym < 2; ++sym) {
     std::vector<uint32_t> cnt(n), lo(n, 0);
     if (sym) {
-      PG(pg_eps_slots_sym(d_planes, npad, n, l, PG_BITS_5, PG_CMP_LE, eps, cap, d_sidx, d_sw, d_cnt, d_lo, nullptr));
+      PG(pg_eps_slots_sym(d_planes, npad, n, l, PG_BITS_5, PG_CMP_LE, eps, cap, d_sidx, d_sw, d_cnt, d_lo, d_ws, nullptr));
       HIP(hipMemcpy(lo.data(), d_lo, n * 4, hipMemcpyDeviceToHost));
     } else {
-      PG(pg_eps_slots(d_planes, npad, 0, n, d_planes, npad, n, l, PG_BITS_5, PG_CMP_LE, eps, cap, d_sidx, d_sw, d_cnt, nullptr));
+      PG(pg_eps_slots(d_planes, npad, 0, n, d_planes, npad, n, l, PG_BITS_5, PG_CMP_LE, eps, cap, d_sidx, d_sw, d_cnt, d_ws, nullptr));
     }
     HIP(hipMemcpy(cnt.data(), d_cnt, n * 4, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; ++i) cnt[i] += lo[i];           // totals (a device add in a real host)

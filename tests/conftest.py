@@ -12,6 +12,7 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "one_engine: GPU test that does not run once per all-pairs engine")
 
 
 def load_golden(name):

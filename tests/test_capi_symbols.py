@@ -46,7 +46,7 @@ def test_argument_validation_without_gpu():
     """Library-side argument checks return PG_E_* before any launch."""
     from prograph_amd import _native
     lib = _native.lib()
-    rc = lib.pg_knn_hamming(None, 256, 0, 1, None, 256, 1, 16, 5, 4, None, None, None)
+    rc = lib.pg_knn_hamming(None, 256, 0, 1, None, 256, 1, 16, 5, 4, None, None, None, None)
     assert rc == -1 and b"bad argument" in lib.pg_last_error()
     rc = lib.pg_pack_planes(ctypes.c_void_p(16), 1, 4, 300, 300, None, 5, ctypes.c_void_p(16), 256, ctypes.c_void_p(16), None)
     assert rc == -2

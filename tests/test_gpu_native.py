@@ -20,12 +20,25 @@ SETS = ["ref_synthetic_csv", "synth_n1000_l32", "synth_n2085_l64", "synth_n515_l
 BITS = [5, 8]
 
 
-@pytest.fixture(autouse=True, params=["valu", "mfma"])
+def pytest_generate_tests(metafunc):
+    """Tests that reach an all-pairs engine run on both of them: pg_nsq.h (stage 1 on the VALU) and pg_mm.h
+    (stage 1 on the matrix cores) - left alone the library picks by size (MFMA from 40 000 / 60 000 rows on).
+    Tests marked `one_engine` (no all-pairs launch, or they choose the engine themselves) run once."""
+    if "engine" in metafunc.fixturenames:
+        once = metafunc.definition.get_closest_marker("one_engine") is not None
+        metafunc.parametrize("engine", ["auto"] if once else ["valu", "mfma"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
 def engine(request, monkeypatch):
-    """Every test runs on both all-pairs engines: pg_nsq.h (stage 1 on the VALU) and pg_mm.h (stage 1 on
-    the matrix cores).  Left alone the library picks by size (MFMA from 65 536 rows on)."""
-    monkeypatch.setenv("PG_ENGINE", request.param)
+    if request.param == "auto":
+        monkeypatch.delenv("PG_ENGINE", raising=False)
+    else:
+        monkeypatch.setenv("PG_ENGINE", request.param)
     return request.param
+
+
+one_engine = pytest.mark.one_engine
 
 
 @pytest.fixture(scope="module")
@@ -105,6 +118,7 @@ def test_row_window_equals_full(nat):
         assert np.array_equal(kd.cpu().numpy(), g["knn16_w"][r0:r0 + nr])
 
 
+@one_engine
 def test_dense_kats(nat):
     g = load_golden("hamming_kats")
     for i in range(6):       # r4/r5 are 130 / 200 tokens wide: native with 5 bit planes only
@@ -124,6 +138,7 @@ def test_dense_kats(nat):
         assert out.dtype == dt and np.array_equal(out.cpu().numpy().astype(np.int64), g["wide_out"])
 
 
+@one_engine
 def test_dense_vs_oracle_all_q(nat):
     from oracle import prograph_oracle as O
     rng = np.random.RandomState(5)
@@ -187,6 +202,7 @@ def test_eps_float_thresholds_and_comparators(nat):
             assert np.array_equal(ip, ref[0]) and np.array_equal(ix, ref[1]) and np.array_equal(w, ref[2].astype(np.uint8)), (op, eps)
 
 
+@one_engine
 def test_index_flags_and_compaction(nat):
     g = load_golden("ref_synthetic_csv")
     tok = g["tokens"]
@@ -214,6 +230,7 @@ def test_index_flags_and_compaction(nat):
     assert np.array_equal(got, np.nonzero(f)[0])
 
 
+@one_engine
 def test_pack_flags_and_errors(nat):
     tok = np.array([[1, 2, 200], [3, 4, 5]], dtype=np.int64)
     assert nat.pack(torch.from_numpy(tok)).bits == 8 and nat.pack(torch.from_numpy(tok[1:])).bits == 5
@@ -277,6 +294,70 @@ def test_full_size_properties(nat, cfg):
         assert np.array_equal(w[indptr[r]:indptr[r + 1]], d[cols])
         order = np.argsort(d, kind="stable")[1:k + 1]
         assert np.array_equal(kidx[r], order) and np.array_equal(kd[r], d[order])
+
+
+@one_engine
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_full_matrix_parity_at_the_headline_sizes(nat, cfg):
+    """EVERY entry against the oracle, once, at BASELINE.json configs[1] / configs[2] with the library's own choice of
+    engine and path (cfg3: persistent-wave MFMA engine, 64-row passes, symmetric eps): all N x 16 kNN indices and
+    distances and the complete eps <= 2 CSR.  The oracle is the C leg's vectorised form (tests/test_oracle.py pins it
+    to the scalar leg -> Python oracle -> reference goldens): 4e10 pairs take well under a minute of host time."""
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    N, L, eps, k = (50_000, 32, 2, 16) if cfg == "cfg2" else (200_000, 64, 2, 16)
+    tok = synth.clustered_tokens(N, L)
+    p = nat.pack(torch.from_numpy(tok), bits=5)
+    kidx, kd = nat.knn_graph(p, p, k)
+    indptr, idx, w = nat.eps_graph(p, p, nat.CMP_LE, eps, cap=256)
+    torch.cuda.synchronize()
+    ridx, rd = C.knn(tok, k, fast=True)
+    assert np.array_equal(kidx.cpu().numpy(), ridx), f"{cfg}: kNN indices differ in {int((kidx.cpu().numpy() != ridx).any(axis=1).sum())} rows"
+    assert np.array_equal(kd.cpu().numpy(), rd)
+    rp, ri, rw = C.eps_csr(tok, 0, eps, fast=True)
+    assert np.array_equal(indptr.cpu().numpy(), rp)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(w.cpu().numpy(), rw)
+
+
+@one_engine
+def test_full_windows_on_dense_data_and_on_the_sharded_slice(nat):
+    """Whole 4 096-row windows against the oracle where a full matrix is out of reach on the host: (i) cfg3's shape on
+    DENSE data (one cluster: the folded / exact forms of the engine), (ii) rank 3's block of BASELINE.json configs[3]
+    (125 000 rows x 1 000 000 columns), (iii) a 400 000-row launch of the same problem, the window straddling the
+    4 096th pass, i.e. reaching into the passes the persistent waves fetch through the counter."""
+    from oracle import c_oracle as C
+    from prograph_amd import synth, sharded
+    k = 16
+    tok = synth.clustered_tokens(200_000, 64, members=200_000)
+    p = nat.pack(torch.from_numpy(tok), bits=5)
+    kidx, kd = nat.knn_graph(p, p, k)
+    torch.cuda.synchronize()
+    r0 = 150_016
+    ridx, rd = C.knn(tok, k, row0=r0, nrows=4096, fast=True)
+    assert np.array_equal(kidx[r0:r0 + 4096].cpu().numpy(), ridx) and np.array_equal(kd[r0:r0 + 4096].cpu().numpy(), rd)
+    del p, kidx, kd
+    N = 1_000_000
+    tok = synth.clustered_tokens(N, 64)
+    p = nat.pack(torch.from_numpy(tok), bits=5)
+    lo, hi = sharded.row_block(N, 8, 3)
+    kidx, kd = nat.knn_graph(p, p, k, row0=lo, nrows=hi - lo)
+    indptr, idx, w = nat.eps_graph(p, p, nat.CMP_LE, 2, row0=lo, nrows=hi - lo, cap=64)
+    torch.cuda.synchronize()
+    w0 = 60_000                                               # rows of the block (3 907 passes: one round of the grid)
+    ridx, rd = C.knn(tok, k, row0=lo + w0, nrows=4096, fast=True)
+    assert np.array_equal(kidx[w0:w0 + 4096].cpu().numpy(), ridx) and np.array_equal(kd[w0:w0 + 4096].cpu().numpy(), rd)
+    rp, ri, rw = C.eps_csr(tok, 0, 2, row0=lo + w0, nrows=4096, fast=True)
+    ip = indptr.cpu().numpy()
+    assert np.array_equal(ip[w0:w0 + 4097] - ip[w0], rp)
+    assert np.array_equal(idx[ip[w0]:ip[w0 + 4096]].cpu().numpy(), ri) and np.array_equal(w[ip[w0]:ip[w0 + 4096]].cpu().numpy(), rw)
+    del kidx, kd, indptr, idx, w
+    # (iii) a launch longer than one round of the grid: 400 000 rows = 6 250 passes of 64 rows on 4 096 wave slots; the
+    # window straddles pass 4 096, the first one a persistent wave fetches through the launch's counter (workspace)
+    kidx, kd = nat.knn_graph(p, p, k, row0=0, nrows=400_000)
+    torch.cuda.synchronize()
+    w0 = 4096 * 64 - 2048
+    ridx, rd = C.knn(tok, k, row0=w0, nrows=4096, fast=True)
+    assert np.array_equal(kidx[w0:w0 + 4096].cpu().numpy(), ridx) and np.array_equal(kd[w0:w0 + 4096].cpu().numpy(), rd)
 
 
 @pytest.mark.parametrize("sym", ["0", "1"])
@@ -495,6 +576,7 @@ def test_knn_optimistic_cap_is_exact(nat, monkeypatch, guess):
     assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d.cpu().numpy(), rd)
 
 
+@one_engine
 def test_c_abi_without_python(nat):
     """tests/capi/capi_check.cpp: a plain C++ host (hipMalloc, default stream, the declarations of
     include/prograph_hip.h, no Python, no torch) drives pack -> kNN -> eps CSR through both the
@@ -569,6 +651,7 @@ def test_cfg5_full_size_properties(nat):
         assert np.array_equal(idx[r0:r0 + 16], ridx) and np.array_equal(d[r0:r0 + 16], rd), r0
 
 
+@one_engine
 def test_hamming_operator_cache_tracks_in_place_edits(nat):
     """hamming() remembers the packed form of a device-resident X across calls (the reference's
     batch loop passes the same X every time); an in-place edit of X must invalidate it."""
@@ -589,6 +672,7 @@ def test_hamming_operator_cache_tracks_in_place_edits(nat):
     assert np.array_equal(hamming(X, Y).cpu().numpy(), O.hamming(Xh, Y.cpu().numpy()).numpy())
 
 
+@one_engine
 @pytest.mark.parametrize("d,hi", [(256, 21), (700, 21), (129, 256), (300, 256), (1000, 256)])
 def test_hamming_operator_long_sequences(nat, d, hi):
     """Sequences longer than one record: the operator sums the dense kernel over column segments
@@ -708,6 +792,7 @@ def test_dense_mutant_library_is_exact(nat, engine, case):
     assert np.array_equal(indeg, np.diff(indptr))
 
 
+@one_engine
 def test_allgather_tokens_through_the_c_abi(nat):
     """pg_comm_* / pg_allgather_tokens: RCCL bound inside the library, no torch.distributed on the data path.
     One rank (this box has one GPU): the gather of a padded shard must reproduce it."""
@@ -721,6 +806,7 @@ def test_allgather_tokens_through_the_c_abi(nat):
         nat.comm_destroy(comm)
 
 
+@one_engine
 def test_minkowski_f16_against_the_reference(nat):
     """
     SURVEY.md §8 f2 through the C ABI: pg_pack_f16 + pg_minkowski_dense + pg_f16_knn / pg_f16_eps_* against
@@ -790,6 +876,7 @@ def test_eps_graph_with_more_than_2_31_entries(nat, engine):
         assert np.array_equal(idx[a:b].cpu().numpy(), cols) and np.array_equal(w[a:b].cpu().numpy(), d[cols]), r
 
 
+@one_engine
 @pytest.mark.gpu
 def test_mfma_fp4_operand_layout_and_exactness():
     """tools/ubench/mfma_fp4.hip: v_mfma_f32_32x32x64_f8f6f4 with FP4 operands against a CPU product - the lane /
@@ -805,12 +892,13 @@ def test_mfma_fp4_operand_layout_and_exactness():
     assert out.returncode == 0 and "layout confirmed" in out.stdout, out.stdout + out.stderr
 
 
-def test_concurrent_launches_on_two_streams(nat):
+@one_engine
+def test_concurrent_launches_on_two_streams(nat, monkeypatch):
     """The MFMA engine hands its passes out through a per-launch counter (persistent waves): launches that overlap
     on different streams must not share one.  Two kNN sweeps of different row windows run concurrently, several
     times over, and are compared with serial runs."""
     from prograph_amd import synth
-    os.environ["PG_ENGINE"] = "mfma"
+    monkeypatch.setenv("PG_ENGINE", "mfma")
     tok = synth.clustered_tokens(150000, 64, seed=5)
     p = _planes(nat, tok, 5)
     ref_a = nat.knn_graph(p, p, 8, row0=0, nrows=140000)
@@ -827,6 +915,50 @@ def test_concurrent_launches_on_two_streams(nat):
         assert torch.equal(b[0], ref_b[0]) and torch.equal(b[1], ref_b[1])
 
 
+@one_engine
+def test_many_short_launches_beside_a_long_one(nat, monkeypatch):
+    """The pass counter of a launch lives in caller-owned workspace (ABI 3; it used to be one of a ring of 256 words
+    inside the library, so the 257th launch after a still-running one shared its counter).  One long MFMA-engine
+    launch on stream A, 300 short ones on stream B meanwhile; both must equal their serial results."""
+    from prograph_amd import synth
+    monkeypatch.setenv("PG_ENGINE", "mfma")
+    big = _planes(nat, synth.clustered_tokens(400000, 64, seed=11), 5)
+    small = _planes(nat, synth.clustered_tokens(600, 64, seed=12, members=64), 5)
+    ref_big = nat.knn_graph(big, big, 8)
+    ref_small = nat.knn_graph(small, small, 8)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(sa):
+        a = nat.knn_graph(big, big, 8)
+    outs = []
+    with torch.cuda.stream(sb):
+        for _ in range(300):
+            outs.append(nat.knn_graph(small, small, 8))
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], ref_big[0]) and torch.equal(a[1], ref_big[1])
+    for o in outs:
+        assert torch.equal(o[0], ref_small[0]) and torch.equal(o[1], ref_small[1])
+
+
+@one_engine
+def test_second_device_when_present(nat, monkeypatch):
+    """Nothing on the device is shared between launches: the same calls work on another GPU of the process
+    (the pass counters used to be allocated once, on whichever device came first)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU")
+    from prograph_amd import synth
+    monkeypatch.setenv("PG_ENGINE", "mfma")
+    tok = synth.clustered_tokens(70000, 64, seed=3)
+    res = []
+    for d in (0, 1):
+        with torch.cuda.device(d):
+            p = _planes(nat, tok, 5)
+            idx, dist = nat.knn_graph(p, p, 8)
+            res.append((idx.cpu(), dist.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@one_engine
 def test_bench_json_line_contract():
     """bench.py prints ONE JSON line with the driver's keys, a roofline object (bound / achieved / peak / unit /
     frac / traffic) and a cpu_baseline slot; run on the smallest workload with two steps."""

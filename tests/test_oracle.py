@@ -164,6 +164,31 @@ def test_levenshtein_definition():
             assert got == min(full, band + 1) if full <= band else got == band + 1
 
 
+def test_fast_c_leg_matches_the_scalar_leg():
+    """oracle.c's vectorised leg (32 bytes per compare; used for the full 200 000 x 200 000 checks on the GPU box) is
+    pinned to its scalar leg - itself pinned to the Python oracle and so to the reference's golden vectors - on ragged
+    lengths, duplicates, every comparator, row windows, and on the golden sets directly."""
+    from oracle import c_oracle as C
+    rng = np.random.RandomState(3)
+    for l in [1, 7, 8, 9, 31, 32, 33, 40, 63, 64, 65, 100, 128, 255]:
+        tok = rng.randint(0, 5, size=(257, l)).astype(np.uint8)
+        tok[5] = tok[200]
+        tok[17, : l // 2] = tok[3, : l // 2]
+        for cmp in range(5):
+            a, b = C.eps_csr(tok, cmp, 2.5, row0=3, nrows=200), C.eps_csr(tok, cmp, 2.5, row0=3, nrows=200, fast=True)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (l, cmp)
+        for k in (1, 4, 19, 300):
+            a, b = C.knn(tok, k), C.knn(tok, k, fast=True)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (l, k)
+    for name in SETS:
+        g = load_golden(name)
+        ix, d = C.knn(g["tokens"], 16, fast=True) if "knn16_idx" in g.files else (None, None)
+        if ix is not None:
+            assert np.array_equal(ix, g["knn16_idx"]) and np.array_equal(d, g["knn16_w"])
+        ip, ii, w = C.eps_csr(g["tokens"], 0, 2, fast=True)
+        assert np.array_equal(ip, g["eps2_indptr"]) and np.array_equal(ii, g["eps2_indices"]) and np.array_equal(w, g["eps2_weights"])
+
+
 def test_c_oracle_matches_python_oracle():
     """The C leg (oracle/oracle.c) is pinned to the Python oracle, which is pinned to the reference."""
     from oracle import c_oracle as C

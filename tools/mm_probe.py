@@ -33,7 +33,7 @@ if what == "landscape":
         L_ = nat.lib()
         def sym():
             nat._check(L_.pg_eps_slots_sym(nat._ptr(p.buf), p.npad, p.n, p.g * 32, p.bits, nat.CMP_LE, 2.0, cap, nat._ptr(si), nat._ptr(sw),
-                                           nat._ptr(cnt), nat._ptr(cl), nat._stream()), "sym")
+                                           nat._ptr(cnt), nat._ptr(cl), nat._ptr(nat.workspace(N, dev)), nat._stream()), "sym")
         line = [name]
         for eng in ("valu", "mfma"):
             os.environ["PG_ENGINE"] = eng
