@@ -22,8 +22,12 @@ Workloads (--workload):
   cfg5  N=200 000, variable length 96..128, banded Levenshtein (band 8), kNN k=8 — build defined
   cfg3d cfg3's shape on DENSE data (one cluster: a mutant library around one seed, every pair within 6)
 
-With one GPU and the default workload the line also carries `extra`: short runs of cfg2, cfg3d and
-cfg5 in the same invocation (their own ms_per_step / kernel_ms / value).
+  cfg3b8 cfg3's shape packed with 8 bit planes (any byte alphabet: the engine's HammingMetric<2,8> instances)
+  mink64 / mink1280  N=50 000 fp16 embeddings of D = 64 / 1280, Minkowski p=2 kNN k=16
+
+With one GPU and the default workload the line also carries `extra`: short runs of cfg2, cfg3d, cfg5, cfg3b8,
+mink64 and mink1280 in the same invocation (their own ms_per_step / kernel_ms / value), mirrored - workload,
+ms_per_step, kernel_ms, frac - in `roofline.other_workloads` (the driver keeps top-level keys only).
 
 roofline: the all-pairs kernel is bound by vector-instruction issue, not by HBM (the operand matrix is
 cache resident): `frac` = wave-instructions per second / the SIMD-32 issue peak, with the per-launch
@@ -61,6 +65,10 @@ WORKLOADS = {
     "cfg4": dict(N=1_000_000, L=64, mode="knn", eps=None, k=16, shards=8),
     # build-defined (no reference counterpart, parity unpinned): variable length 96..128, band 8
     "cfg5": dict(N=200_000, L=128, mode="lev", eps=None, k=8, shards=1, band=8),
+    "cfg3b8": dict(N=200_000, L=64, mode="knn", eps=None, k=16, shards=1, bits=8),
+    # Minkowski p = 2 on fp16 embeddings: L = embedding dimension
+    "mink64": dict(N=50_000, L=64, mode="mink", eps=None, k=16, shards=1),
+    "mink1280": dict(N=50_000, L=1280, mode="mink", eps=None, k=16, shards=1),
 }
 
 
@@ -71,7 +79,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto"] + list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the cfg2 / cfg3d / cfg5 sub-records")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sub-records (cfg2, cfg3d, cfg5, cfg3b8, mink64, mink1280)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU budget of the baseline sample")
     return ap.parse_args()
 
@@ -158,6 +166,10 @@ def run_workload(name, G, rank, dev, use_dist, backend, steps, warmup, want_pcie
 
     # synthetic input, resident in HBM before the timed region.  With G > 1 every rank owns its
     # row shard and the full matrix is all-gathered inside the step (the path's one collective).
+    if wl["mode"] == "mink":
+        if G != 1 or use_dist:
+            raise SystemExit("the Minkowski workloads are single-GPU")
+        return run_minkowski(name, wl, dev, steps, warmup)
     if wl["mode"] == "lev":
         if G != 1 or use_dist:
             raise SystemExit("cfg5 is a single-GPU workload")
@@ -201,7 +213,7 @@ def run_workload(name, G, rank, dev, use_dist, backend, steps, warmup, want_pcie
                 kern_ev.append((e0, e1))
             return
         full = c.tok_dev if not use_dist else sharded.allgather_tokens(shard_dev, N)
-        planes = _native.pack(full, bits=5, check=False)        # validity word read once after the timed steps
+        planes = _native.pack(full, bits=wl.get("bits", 5), check=False)   # validity word read once after the timed steps
         c.flags.append(planes.flags)
         e0.record()
         if wl["mode"] == "eps" and lo == 0 and rows_local == N and os.environ.get("PG_EPS_SYM", "auto") != "0":
@@ -282,20 +294,65 @@ def run_workload(name, G, rank, dev, use_dist, backend, steps, warmup, want_pcie
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in kern_ev]))
     ms_per_step = elapsed / steps * 1e3
     value = float(rows_local) * N * G * steps / elapsed         # every rank does rows_local x N
-    thr_default = "60000" if (wl["mode"] == "eps" and L <= 32) else "40000"     # pg_api.hip: use_mm_engine
+    thr_default = "20000" if wl["mode"] == "knn" else ("60000" if L <= 32 else "40000")     # pg_api.hip: use_mm_engine
     engine = "mfma" if rows_local >= int(os.environ.get("PG_ENGINE_MIN_ROWS", thr_default)) else "valu"
     engine = os.environ.get("PG_ENGINE", engine)
+    if wl["mode"] == "lev":
+        engine = "valu"                       # the bag filter runs on pg_nsq_kernel<BagMetric> (SAD is not bilinear)
     rec = {"name": name, "N": N, "L": L, "k": k, "rows_local": rows_local, "kern_ms": kern_ms, "ms_per_step": ms_per_step,
            "value": value, "pcie_ms": pcie_ms, "result": result, "engine": engine}
     return rec, tok_host, wl
 
 
+def run_minkowski(name, wl, dev, steps, warmup):
+    """kNN graph of N fp16 embeddings under Minkowski p = 2 with the reference's fp16 rounding: per block of rows the
+    distance block (pg_minkowski_dense) and the canonical ranks 1..k (pg_f16_knn), as Prograph._build_graph_minkowski
+    walks them.  Kernel time = the HIP-event time of all launches of a step."""
+    from prograph_amd import _native
+    N, D, k = wl["N"], wl["L"], wl["k"]
+    g = torch.Generator(device="cpu").manual_seed(20260104)
+    X = torch.randn((N, D), generator=g, dtype=torch.float32).to(torch.float16).to(dev)
+    rows_per_block = max(64, min(N, (1 << 27) // N))
+    kern_ev = []
+
+    def step(record):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        xp = _native.pack_f16(X)
+        last = None
+        for r0 in range(0, N, rows_per_block):
+            yp = _native.pack_f16(X[r0:r0 + rows_per_block])
+            block = _native.minkowski_dense(xp, yp)
+            last = _native.f16_knn(block, k, first=1)
+        e1.record()
+        if record:
+            kern_ev.append((e0, e1))
+        return last
+
+    for _ in range(warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kern_ev]))
+    rec = {"name": name, "N": N, "L": D, "k": k, "rows_local": N, "kern_ms": kern_ms, "ms_per_step": elapsed / steps * 1e3,
+           "value": float(N) * N * steps / elapsed, "pcie_ms": None, "result": {}, "engine": "valu (pg_minkowski_dense)"}
+    return rec, None, wl
+
+
 def workload_text(rec, wl, G):
+    if wl["mode"] == "mink":
+        return f"{rec['name']}: N={rec['N']} fp16 embeddings D={rec['L']}, Minkowski p=2 (fp16 rounding of the reference), kNN k={rec['k']}"
     N, L, k = rec["N"], rec["L"], rec["k"]
     kind = (f"kNN k={k}" if wl["mode"] == "knn" else
             f"banded Levenshtein band={wl.get('band')} kNN k={k} (build defined, parity unpinned)" if wl["mode"] == "lev"
             else f"eps d<={wl['eps']} full CSR")
     data = ", dense data (one cluster)" if wl.get("dense") else ""
+    if wl.get("bits") == 8:
+        data += ", packed with 8 bit planes (byte alphabet)"
     shard = (f", row-block sharded, {rec['rows_local']} rows/GPU x {N} columns, RCCL all-gather in step"
              if G > 1 or wl["shards"] > 1 else "")
     return f"{rec['name']}: N={N} L={L} {'Levenshtein' if wl['mode'] == 'lev' else 'Hamming'}, {kind}{data}{shard}"
@@ -305,12 +362,28 @@ def roofline(rec, wl, pmc, sha):
     """VALU-issue roofline of the dominant kernel, instruction counts from the committed PMC pass of
     the same sources, time from this run."""
     k, rows_local, N, L = rec["k"], rec["rows_local"], rec["N"], rec["L"]
+    if wl["mode"] == "mink":
+        # VALU bound by construction (csrc/pg_mink.hip): 3 vector instructions per 2 elements per pair (v_pk_add_f16,
+        # v_pk_mul_f16, v_dot2c_f32_f16); the algorithmic count, no counters needed
+        valu = 1.5 * L * float(N) * N / 64.0
+        achieved = valu / (rec["kern_ms"] * 1e-3)
+        alg_bytes = float(N) * N * (2 * L + 2)
+        return {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instructions/s", "frac": achieved / VALU_PEAK,
+                "traffic": None, "kernel": "pg_minkowski_dense (+ pg_pack_f16, pg_f16_knn)", "kernel_ms": rec["kern_ms"],
+                "valu_wave_instr_per_launch": valu,
+                "hbm_equivalent": {"achieved_GBs": alg_bytes / (rec["kern_ms"] * 1e-3) / 1e9, "algorithmic_bytes": alg_bytes,
+                                   "note": "2*D bytes of fp16 operand per ordered pair + the fp16 distance"},
+                "note": "algorithmic instruction count 1.5 * D * N^2 / 64 (not a counter); kernel_ms spans all launches of a step"}
     out_bytes = 5 * k * rows_local if wl["mode"] in ("knn", "lev") else 8 * (rows_local + 1) + 5 * rec["result"].get("nnz", 0)
     alg_bytes = float(rows_local) * N * L + rows_local * L + out_bytes      # SURVEY.md §8-d, per launch
     hbm_eq = alg_bytes / (rec["kern_ms"] * 1e-3) / 1e9
     p = pmc.get(rec["name"]) or {}
     fresh = bool(p) and p.get("kernel_src_sha") == sha
     valu = p.get("valu_wave_instr_per_launch") if fresh else None
+    if wl["mode"] == "lev" and fresh:
+        # kernel_ms spans ALL launches of a Levenshtein step, so does the instruction count (profile + bag filter +
+        # pack + exact distances / selection, summed per step by tools/summarize_prof.py)
+        valu = p.get("valu_wave_instr_per_step_all_kernels")
     mfma = p.get("mfma_instr_per_launch") if fresh else None
     achieved = valu / (rec["kern_ms"] * 1e-3) if valu else None
     r = {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instructions/s",
@@ -405,10 +478,11 @@ def main():
         # the other single-GPU configurations, a few steps each, in the same invocation
         if G == 1 and not use_dist and a.workload == "auto" and not a.no_extra:
             extra = []
-            for sub in ("cfg2", "cfg3d", "cfg5"):
+            for sub in ("cfg2", "cfg3d", "cfg5", "cfg3b8", "mink64", "mink1280"):
                 torch.cuda.empty_cache()
-                srec, _, swl = run_workload(sub, 1, 0, dev, False, backend, steps=5, warmup=2, want_pcie=False)
-                e = {"workload": workload_text(srec, swl, 1), "steps": 5, "warmup": 2, "ms_per_step": srec["ms_per_step"],
+                nst, nwu = (2, 1) if sub == "mink1280" else (5, 2)
+                srec, _, swl = run_workload(sub, 1, 0, dev, False, backend, steps=nst, warmup=nwu, want_pcie=False)
+                e = {"workload": workload_text(srec, swl, 1), "steps": nst, "warmup": nwu, "ms_per_step": srec["ms_per_step"],
                      "value": srec["value"], "unit": "sequence-pairs/s", "engine": srec["engine"],
                      "roofline": roofline(srec, swl, pmc, sha)}
                 if swl["mode"] == "eps":
@@ -418,6 +492,11 @@ def main():
                     e["candidates"] = srec["result"].get("candidates")
                 extra.append(e)
             line["extra"] = extra
+            # (the driver's record keeps top-level keys only: the sub-records' essentials ride inside `roofline`)
+            line["roofline"]["other_workloads"] = [
+                {"workload": e["workload"], "ms_per_step": e["ms_per_step"], "kernel_ms": e["roofline"]["kernel_ms"],
+                 "value": e["value"], "engine": e["engine"], "bound": e["roofline"]["bound"], "frac": e["roofline"]["frac"],
+                 "kernel": e["roofline"]["kernel"]} for e in extra]
         if not use_dist and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tok_host, wl, a.cpu_seconds)
         else:

@@ -505,9 +505,10 @@ static bool use_mm_engine(int64_t nrows, int l = 64, bool knn = true) {
     if (!strcmp(e, "mfma")) return true;
     if (!strcmp(e, "valu")) return false;
   }
-  // tools/engine_crossover.py: kNN crosses at ~32k rows, eps at ~40k; eps graphs of sequences of one group
-  // (L <= 32: only 32 signature bits) at ~60k (N = 50k L = 32: VALU engine 0.70 ms, MFMA engine 0.75)
-  const long long dflt = (!knn && l <= 32) ? 60000 : 40000;
+  // eps crosses at ~40k rows (tools/engine_crossover.py), eps graphs of sequences of one group (L <= 32: only 32
+  // signature bits) at ~60k (N = 50k L = 32: VALU engine 0.68 ms, MFMA engine 0.80); kNN, since the MFMA engine queues
+  // its candidates lane-parallel, at ~20k (profiles/r03_engine_landscape.txt: N = 20k 0.30 vs 0.32 ms, 50k 0.59 vs 1.19)
+  const long long dflt = knn ? 20000 : (l <= 32 ? 60000 : 40000);
   const long long thr = getenv("PG_ENGINE_MIN_ROWS") ? atoll(getenv("PG_ENGINE_MIN_ROWS")) : dflt;
   return nrows >= thr;
 }

@@ -25,6 +25,7 @@ for wl in wls:
         "kernel_src_sha": summ.get("kernel_src_sha"),
         "valu_issue_frac": summ.get("valu_issue_frac_of_peak"),
         "valu_wave_instr_per_launch": summ["counters"].get("SQ_INSTS_VALU"),
+        "valu_wave_instr_per_step_all_kernels": summ.get("valu_wave_instr_per_step_all_kernels"),
         "salu_instr_per_launch": summ["counters"].get("SQ_INSTS_SALU"),
         "mfma_instr_per_launch": summ["counters"].get("SQ_INSTS_MFMA"),
         "wait_any_frac_of_wave_cycles": (summ["counters"].get("SQ_WAIT_ANY", 0) / summ["counters"]["SQ_WAVE_CYCLES"]) if summ["counters"].get("SQ_WAVE_CYCLES") else None,

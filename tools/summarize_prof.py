@@ -51,6 +51,13 @@ for f in pmc_files:
             res["grid"] = int(r["Grid_Size"]); res["wg"] = int(r["Workgroup_Size"])
     for k, v in agg.items():
         res["counters"][k] = sum(v) / len(v)
+    # every kernel of a step (multi-kernel workloads: cfg5): per-kernel mean counter value x launches per step
+    allk = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        allk[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for kn, cs in allk.items():
+        for cn, v in cs.items():
+            res.setdefault("per_kernel_counters", {}).setdefault(kn[:80], {})[cn] = {"mean": sum(v) / len(v), "launches": len(v)}
 c = res["counters"]
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     # MI355X_MICROARCH.md §HBM: counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of
@@ -66,6 +73,11 @@ if "SQ_INSTS_VALU" in c and res["kernel"]:
     res["valu_issue_frac_of_4cycle_rate"] = res["valu_wave_instr_per_s"] / (256 * 4 * 2.4e9 / 4)
 if "SQ_INSTS_MFMA" in c and res["kernel"]:
     res["mfma_pipe_busy_frac"] = c["SQ_INSTS_MFMA"] * 32.0 / (256 * 4 * 2.4e9 * res["kernel"]["avg_ns"] * 1e-9)
+if "per_kernel_counters" in res:
+    # SQ_INSTS_VALU of ALL kernels of one step: the PMC passes ran `steps + warmup` = 4 steps of the workload
+    steps_profiled = 4
+    res["valu_wave_instr_per_step_all_kernels"] = sum(v["SQ_INSTS_VALU"]["mean"] * v["SQ_INSTS_VALU"]["launches"]
+                                                      for v in res["per_kernel_counters"].values() if "SQ_INSTS_VALU" in v) / steps_profiled
 if "TCC_HIT_sum" in c:
     res["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
 print(json.dumps(res, indent=1))
