@@ -112,6 +112,18 @@ int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld
                    void *stream);
 
 /*
+ * pg_pack_bytes — tokenise AND pack on the device.
+ * Replaces `Prograph.tokenize` (prograph/prograph.py:454-474: one np.where pass per alphabet letter over the
+ * fixed-width byte view of the sequence strings, table :127) together with the staging above: `src` is that byte
+ * view, (n, width) uint8 row-major (numpy 'S<width>' storage: short sequences are NUL padded), `lut256` the
+ * 256-entry letter table on the device (letter j of the alphabet -> j+1, everything else -> 0).
+ *   tokens_out optional uint8 (n, width) row-major: the token matrix itself, for hosts that expose it
+ *   flags      as in pg_pack_planes (set when a table entry does not fit `bits` planes)
+ */
+int pg_pack_bytes(const uint8_t *src, int64_t n, int width, int64_t ld, const int64_t *rows, const uint8_t *lut256,
+                  int bits, void *planes, int64_t npad, uint8_t *tokens_out, uint32_t *flags, void *stream);
+
+/*
  * pg_hamming_dense — all-pairs Hamming distance matrix.
  * Replaces `torch.sum(X != Y[:,None,:], axis=2)` (prograph/distance/hamming.py:34;
  * K2+K3 of SURVEY.md §2.2).  out[m*ldo + n] = #{j : Y[m,j] != X[n,j]}, (M,N) like the

@@ -26,7 +26,7 @@ MAX_L, MAX_L_5BIT, MAX_K, MAX_K_ROUNDS, MAX_N_KNN, LEV_MAX_BAND = 128, 255, 63, 
 # every symbol include/prograph_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
     "pg_version", "pg_last_error", "pg_device_info", "pg_npad", "pg_ngroups", "pg_nchunks", "pg_planes_bytes", "pg_workspace_bytes",
-    "pg_pack_planes",
+    "pg_pack_planes", "pg_pack_bytes",
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
     "pg_eps_compact", "pg_eps_fill_rows", "pg_eps_slots_sym", "pg_eps_compact_sym", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
     "pg_lev_profile", "pg_lev_candidates", "pg_lev_candidates_sym", "pg_lev_knn", "pg_csr_row_stats",
@@ -83,6 +83,7 @@ def _load():
         lib.pg_workspace_bytes.argtypes = [_i64]
         lib.pg_device_info.argtypes = [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32]
         lib.pg_pack_planes.argtypes = [_vp, _i32, _i64, _i32, _i64, _vp, _i32, _vp, _i64, _vp, _vp]
+        lib.pg_pack_bytes.argtypes = [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]
         lib.pg_hamming_dense.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i64, _i32, _vp]
         lib.pg_eps_slots.argtypes = [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _dbl, _i32,
                                      _vp, _vp, _vp, _vp, _vp]
@@ -250,6 +251,37 @@ def pack(tokens, rows=None, bits=None, width=None, check=True):
     if check:
         planes.ensure_valid()
     return planes
+
+
+def pack_bytes(raw, lut, bits=BITS_5, want_tokens=True, check=True):
+    """
+    Tokenise and pack on the device (pg_pack_bytes): `raw` = the fixed-width byte view of the sequence strings,
+    (N, width) uint8 (host array or device tensor), `lut` = 256 table entries (letter -> token, else 0).
+    Returns (Planes, tokens) with tokens = the (N, width) uint8 token matrix on the device, or None.
+    """
+    L = lib()
+    dev = device()
+    if not isinstance(raw, torch.Tensor):
+        raw = torch.from_numpy(np.ascontiguousarray(np.asarray(raw, dtype=np.uint8)))
+    if raw.dim() != 2 or raw.dtype != torch.uint8:
+        raise TypeError("pack_bytes expects a 2-D uint8 byte matrix")
+    raw = raw.to(dev).contiguous()
+    n, width = raw.shape
+    if n == 0 or width == 0:
+        raise ValueError("empty byte matrix")
+    if width > (MAX_L_5BIT if bits == BITS_5 else MAX_L):
+        raise ValueError(f"L={width} exceeds the native limit for {bits} bit planes")
+    lut_t = torch.as_tensor(np.asarray(lut, dtype=np.uint8).reshape(256)).to(dev)
+    np_ = npad(n)
+    buf = torch.empty(planes_bytes(n, width, bits), dtype=torch.uint8, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    tokens = torch.empty((n, width), dtype=torch.uint8, device=dev) if want_tokens else None
+    _check(L.pg_pack_bytes(_ptr(raw), n, width, raw.stride(0), None, _ptr(lut_t), int(bits), _ptr(buf), np_, _ptr(tokens),
+                           _ptr(flags), _stream()), "pg_pack_bytes")
+    planes = Planes(buf, n, width, bits, flags)
+    if check:
+        planes.ensure_valid()
+    return planes, tokens
 
 
 _TORCH_OUT = {1: torch.uint8, 4: torch.int32, 8: torch.int64}

@@ -86,10 +86,15 @@ int64_t pg_workspace_bytes(int64_t nrows) { (void)nrows; return 256; }
 // =======================================================================================
 // pack: row-major tokens -> bit-sliced records in chunk-major order (one thread per sequence)
 // =======================================================================================
+// lut / tokOut (pg_pack_bytes): src holds the fixed-width BYTES of the sequences; token = lut[byte]
+// (the reference's letter table, prograph/prograph.py:127,454-474: unknown bytes and padding -> 0), written row-major
+// to tokOut as well when that is not NULL.
 template <typename T, int B>
 __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src, long long n, int l, long long ld,
                                                       const long long *__restrict__ rows, u32 *__restrict__ planes,
-                                                      long long npad, int ng, int nq, u32 *flags) {
+                                                      long long npad, int ng, int nq, u32 *flags,
+                                                      const unsigned char *__restrict__ lut = nullptr,
+                                                      unsigned char *__restrict__ tokOut = nullptr) {
   const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
   if (s >= npad) return;
   const T *row = nullptr;
@@ -103,7 +108,11 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(const T *__restrict__ src,
       for (int j = 0; j < 32; ++j) {
         const int pos = g * 32 + j;
         if (pos < l) {
-          const long long v = (long long)row[pos];
+          long long v = (long long)row[pos];
+          if (lut) {
+            v = lut[(unsigned char)v];
+            if (tokOut) tokOut[s * (long long)l + pos] = (unsigned char)v;
+          }
           if (v < 0 || v >= (1ll << B)) bad = 1u;
 #pragma unroll
           for (int p = 0; p < B; ++p) pl[p] |= (u32)((v >> p) & 1) << j;
@@ -460,6 +469,26 @@ int pg_pack_planes(const void *src, int elem_bytes, int64_t n, int l, int64_t ld
   }
 #undef PG_PACK
   return launched((int)hipGetLastError(), "pg_pack_kernel");
+}
+
+int pg_pack_bytes(const uint8_t *src, int64_t n, int width, int64_t ld, const int64_t *rows, const uint8_t *lut256, int bits,
+                  void *planes, int64_t npad, uint8_t *tokens_out, uint32_t *flags, void *stream) {
+  if (!src || !lut256 || !planes || !flags || n < 0 || ld < width) return fail(PG_E_BADARG, "pg_pack_bytes: bad argument");
+  if (int rc = check_bits(bits)) return rc;
+  if (int rc = check_l(width, bits, true)) return rc;
+  if (npad < n || npad % 256) return fail(PG_E_BADARG, "pg_pack_bytes: npad must be pg_npad(n)");
+  const int ng = pg_ngroups(width), nq = pg_nchunks(width, bits);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t), s);
+  if (e != hipSuccess) return hipfail(e, "hipMemsetAsync");
+  const dim3 grid((unsigned)((npad + 255) / 256)), block(256);
+  if (bits == 5)
+    pg_pack_kernel<unsigned char, 5><<<grid, block, 0, s>>>(src, n, width, ld, (const long long *)rows, (u32 *)planes, npad, ng, nq,
+                                                            flags, lut256, tokens_out);
+  else
+    pg_pack_kernel<unsigned char, 8><<<grid, block, 0, s>>>(src, n, width, ld, (const long long *)rows, (u32 *)planes, npad, ng, nq,
+                                                            flags, lut256, tokens_out);
+  return launched((int)hipGetLastError(), "pg_pack_kernel(bytes)");
 }
 
 int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad, const void *y_planes, int64_t m, int64_t y_npad,

@@ -66,8 +66,8 @@ class Prograph:
         self.len = len(self)
 
         self.tokens = {aa.encode("utf-8"): i for i, aa in enumerate(self.amino_acids, start=1)}
-        self.tokenized = self.tokenize(self.graph[seqs_col])
         self._planes = {}            # device-resident plane layouts, keyed by representation
+        self.tokenized = self._ingest_tokens(self.graph[seqs_col])
         self._token_dict = None
         self.seq_idxs = dict(zip(self.graph[seqs_col], range(len(self.graph))))   # last duplicate wins
 
@@ -165,21 +165,50 @@ class Prograph:
             wanted.append("Neighbours")
         return data[wanted]
 
-    def tokenize(self, sequences):
-        """
-        Strings -> (N, Lmax) int tokens: letter j of `amino_acids` -> j+1, padding / unknown -> 0
-        (reference :454-474).  One table lookup over the fixed-width byte view instead of one
-        masked pass per letter.
-        """
+    def _byte_view(self, sequences):
+        """The fixed-width byte view of the strings ((N, Lmax) uint8, NUL padded: numpy 'S' storage) and the
+        256-entry letter table (letter j of `amino_acids` -> j+1, everything else -> 0; reference :127)."""
         arr = np.array(sequences, dtype="bytes").reshape(-1)
         width = max(arr.dtype.itemsize, 1)
         table = np.zeros(256, dtype=int)
         for ch, tok in self.tokens.items():
             if len(ch) == 1:
                 table[ch[0]] = tok
-        raw = np.frombuffer(arr.tobytes(), dtype=np.uint8).reshape(len(arr), width) if len(arr) else \
-            np.zeros((0, width), dtype=np.uint8)
+        raw = np.ascontiguousarray(arr).view(np.uint8).reshape(len(arr), width) if (len(arr) and arr.dtype.itemsize) else \
+            np.zeros((len(arr), width), dtype=np.uint8)
+        return raw, table
+
+    def tokenize(self, sequences):
+        """
+        Strings -> (N, Lmax) int tokens: letter j of `amino_acids` -> j+1, padding / unknown -> 0
+        (reference :454-474).  One table lookup over the fixed-width byte view instead of one
+        masked pass per letter.
+        """
+        raw, table = self._byte_view(sequences)
         return table[raw]
+
+    def _ingest_tokens(self, sequences):
+        """
+        The constructor's tokenisation.  With a GPU the byte view goes to the device once and ONE
+        kernel (`pg_pack_bytes`) applies the letter table, bit-slices the tokens into the plane layout the graph
+        kernels read and writes the token matrix: the planes are cached for `build_graph` / `indexing`, the host's
+        `self.tokenized` is that matrix copied back (uint8) and widened - the table pass over N x L bytes on the
+        host is gone.  Without a device (the host-logic tests' fake backend), or beyond the kernels' widths, the host
+        table lookup of `tokenize` is used.
+        """
+        raw, table = self._byte_view(sequences)
+        bits = _native.BITS_5 if len(self.amino_acids) <= 31 else _native.BITS_8
+        limit = _native.MAX_L_5BIT if bits == _native.BITS_5 else _native.MAX_L
+        try:
+            on_gpu = _native.device().type == "cuda" and hasattr(_native, "pack_bytes")
+        except _native.NativeUnavailable:
+            on_gpu = False
+        if not on_gpu or raw.shape[0] == 0 or raw.shape[1] > limit or len(self.amino_acids) > 255:
+            return table[raw]
+        planes, tok = _native.pack_bytes(raw, table.astype(np.uint8), bits=bits, want_tokens=True)
+        self._planes["Tokenized"] = planes
+        self._tok_u8_dev = tok
+        return tok.cpu().numpy().astype(int)
 
     def custom_tokenize(self, seq, tokenizer=None):
         if tokenizer is None:

@@ -231,6 +231,46 @@ def test_index_flags_and_compaction(nat):
 
 
 @one_engine
+def test_device_tokenisation_matches_the_reference(nat):
+    """pg_pack_bytes: letter table + bit slicing in one kernel from the fixed-width byte view.
+    The token matrix equals the oracle's tokenize (reference :454-474) on the reference's own known answers
+    (tests/tests.py:124-133), on unknown letters / empty / ragged strings and on the golden data set; the planes it
+    writes equal those packed from the token matrix (same kNN graph, same dense distances)."""
+    from oracle import prograph_oracle as O
+    aa = O.AMINO_ACIDS
+    table = np.zeros(256, dtype=np.uint8)
+    for j, ch in enumerate(aa, start=1):
+        table[ord(ch)] = j
+    def view(seqs):
+        arr = np.array(seqs, dtype="bytes").reshape(-1)
+        return np.frombuffer(arr.tobytes(), dtype=np.uint8).reshape(len(arr), max(arr.dtype.itemsize, 1))
+    kats = [(["ACA"], [[1, 2, 1]]), (["ACA", "ACC"], [[1, 2, 1], [1, 2, 2]]),
+            (["ACCCACAAA", "ACAA"], [[1, 2, 2, 2, 1, 2, 1, 1, 1], [1, 2, 1, 1, 0, 0, 0, 0, 0]])]
+    for seqs, want in kats:
+        _, tok = nat.pack_bytes(view(seqs), table)
+        assert np.array_equal(tok.cpu().numpy(), np.array(want)) and np.array_equal(np.array(want), O.tokenize(seqs))
+    odd = ["ACDEFGHIKLMNPQRSTVWY", "XYZ-", "", "WWWWWWWWWWWWWWWWWWWWWWWW", "acd", "A" * 255]
+    _, tok = nat.pack_bytes(view(odd), table)
+    assert np.array_equal(tok.cpu().numpy(), O.tokenize(odd))
+    rng = np.random.RandomState(2)
+    letters = np.array(list(aa + "XB-"))
+    seqs = ["".join(rng.choice(letters, size=rng.randint(1, 70))) for _ in range(3000)]
+    p_dev, tok = nat.pack_bytes(view(seqs), table)
+    ref = O.tokenize(seqs)
+    assert np.array_equal(tok.cpu().numpy(), ref)
+    p_host = _planes(nat, ref.astype(np.uint8), 5)
+    assert torch.equal(p_dev.buf, p_host.buf)                       # chunk arrays, signature and fold sections alike
+    for bits in BITS:
+        pb, tk = nat.pack_bytes(view(seqs[:500]), table, bits=bits)
+        assert torch.equal(pb.buf, _planes(nat, tk.cpu().numpy(), bits).buf)
+    with pytest.raises(ValueError):
+        nat.pack_bytes(view(["A" * 256]), table)                    # beyond the 5-plane width
+    big = table.copy(); big[ord("A")] = 77
+    with pytest.raises(ValueError):
+        nat.pack_bytes(view(["ACA"]), big, bits=5)                  # a table entry that does not fit the planes
+
+
+@one_engine
 def test_pack_flags_and_errors(nat):
     tok = np.array([[1, 2, 200], [3, 4, 5]], dtype=np.int64)
     assert nat.pack(torch.from_numpy(tok)).bits == 8 and nat.pack(torch.from_numpy(tok[1:])).bits == 5

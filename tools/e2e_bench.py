@@ -32,9 +32,12 @@ frame = timed("pd.read_csv", lambda: pd.read_csv(path, index_col=0))
 probe = Prograph.__new__(Prograph)
 probe.amino_acids = "ACDEFGHIKLMNPQRSTVWY"
 probe.tokens = {aa.encode("utf-8"): i for i, aa in enumerate(probe.amino_acids, start=1)}
-tokens = timed("tokenize (one table lookup over the byte view)", lambda: probe.tokenize(frame["Sequence"]))
+timed("[round-2 path, for comparison] host tokenize: table lookup over the byte view", lambda: probe.tokenize(frame["Sequence"]))
+raw, table = timed("byte view of the strings (np.array(..., dtype=bytes))", lambda: probe._byte_view(frame["Sequence"]))
+planes, tokdev = timed("H2D + pg_pack_bytes (letter table + bit slicing + signatures on the device)",
+                       lambda: _native.pack_bytes(raw, table.astype(np.uint8), bits=5))
+tokens = timed("token matrix back to the host (uint8 D2H + widen to int)", lambda: tokdev.cpu().numpy().astype(int))
 timed("seq_idxs reverse map (dict of N strings)", lambda: dict(zip(frame["Sequence"], range(len(frame)))))
-planes = timed("H2D + pg_pack_planes (uint8 tokens -> planes + signatures)", lambda: _native.pack(torch.from_numpy(tokens.astype(np.uint8)), bits=5))
 csr = timed("eps<=1 graph: slots + scan + compact (device CSR)", lambda: _native.eps_graph(planes, planes, _native.CMP_LE, 1))
 print(f"    nnz = {csr[1].numel()}")
 from prograph_amd.graph import CSRGraph
