@@ -7,6 +7,8 @@ roofline) for N x N Hamming + adjacency build").
   python -m torch.distributed.run --nproc-per-node G ... bench.py --gpus G --steps K --warmup W
                                                            (default for G > 1: configs[3], N=1M row-block sharded)
 
+(The timed step packs with check=False: the device word that flags a token outside the alphabet is read once after
+the timed steps, not per step - `Prograph._byte_planes` pays that host sync on every pack.)
 A step = one pass of the hot path over one synthetic token matrix that is already resident in
 HBM as row-major uint8 (SURVEY.md §8-d generator): [all-gather of the row shards when G > 1] ->
 plane packing -> the fused all-pairs kernel (Hamming + kNN selection, or Hamming + epsilon

@@ -347,9 +347,12 @@ int pg_f16_eps_fill(const void *dist_f16, int64_t m, int64_t n, int64_t ld, int 
  *                       rank (pad the last block with zero rows); full (nranks*rows_per_rank, l);
  *                       enqueued on `stream`, no host synchronisation
  * RCCL is resolved at run time (the copy the host process already loaded, else the ROCm installation's):
- * a host without librccl.so still loads this library and gets PG_E_COMM from these four calls only.
+ * a host without librccl.so still loads this library and gets PG_E_COMM from these calls only.
+ *   pg_comm_available   1 when this process can bind RCCL (a local check, no communication): hosts let every rank
+ *                       agree on it BEFORE anybody enters the collective pg_comm_init
  */
 #define PG_COMM_ID_BYTES 128
+int pg_comm_available(void);
 int pg_comm_unique_id(void *id128);
 int pg_comm_init(void **comm, int nranks, int rank, const void *id128);
 int pg_comm_destroy(void *comm);

@@ -30,7 +30,7 @@ SYMBOLS = [
     "pg_hamming_dense", "pg_eps_slots", "pg_scan_scratch_bytes", "pg_exclusive_scan",
     "pg_eps_compact", "pg_eps_fill_rows", "pg_eps_slots_sym", "pg_eps_compact_sym", "pg_knn_hamming", "pg_knn_hamming_round", "pg_index_flags", "pg_compact_flags",
     "pg_lev_profile", "pg_lev_candidates", "pg_lev_candidates_sym", "pg_lev_knn", "pg_csr_row_stats",
-    "pg_comm_unique_id", "pg_comm_init", "pg_comm_destroy", "pg_allgather_tokens",
+    "pg_comm_available", "pg_comm_unique_id", "pg_comm_init", "pg_comm_destroy", "pg_allgather_tokens",
     "pg_f16_nchunks", "pg_pack_f16", "pg_minkowski_dense", "pg_f16_knn", "pg_f16_eps_count", "pg_f16_eps_fill",
 ]
 
@@ -475,6 +475,9 @@ def levenshtein_knn(tokens, k, band=8, row0=0, nrows=None, cap=512, return_stats
     counterpart).  `tokens`: (N, L<=128) uint8, tokens 1..31, zero right-padded.
     Returns (idx int32 (nrows,k), dist uint8 (nrows,k)): ranks 1..k of the (d, column) order with
     d = min(edit distance, band+1).
+    Invalid input (a token above 31, an interior zero) raises ValueError - after the candidate pass: the validity
+    word of the profile kernel is read together with the largest candidate count (the step's ONE host sync), so a
+    bad matrix costs one filter sweep before it is rejected (the kernels mask symbols, nothing goes out of bounds).
     """
     L = lib()
     dev = device()
@@ -615,6 +618,14 @@ def f16_eps(block, cmp, eps, similarity=False):
 
 
 COMM_ID_BYTES = 128
+
+
+def comm_available():
+    """Can this process bind RCCL (local check, not a collective)?"""
+    try:
+        return bool(lib().pg_comm_available())
+    except NativeUnavailable:
+        return False
 
 
 def comm_unique_id():

@@ -956,6 +956,8 @@ static int rcclfail(RcclApi *r, ncclResult_t e, const char *where) {
   return PG_E_COMM;
 }
 
+int pg_comm_available(void) { return rccl() ? 1 : 0; }   // local, not a collective: can this process bind RCCL at all?
+
 int pg_comm_unique_id(void *id128) {
   RcclApi *r = rccl();
   if (!r) return fail(PG_E_COMM, "pg_comm_unique_id: librccl.so not found");

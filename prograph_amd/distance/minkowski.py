@@ -16,7 +16,9 @@ from .utils import clean_input
 
 def minkowski(X, Y, p=2, similarity=False):
     X, Y = clean_input(X, Y)
-    if p == 2 and X.dtype == torch.float16 and Y.dtype == torch.float16 and X.is_cuda and Y.is_cuda and X.shape[1] > 0:
+    # (the kernel takes up to 65 535 blocks of 16 rows of Y per launch; empty / wider operands: the torch expression)
+    if (p == 2 and X.dtype == torch.float16 and Y.dtype == torch.float16 and X.is_cuda and Y.is_cuda and X.shape[1] > 0
+            and X.shape[0] > 0 and 0 < Y.shape[0] <= 65535 * 16):
         return _native.minkowski_dense(_native.pack_f16(X), _native.pack_f16(Y), similarity=similarity)
     diff = X - Y[:, None, :]
     distances = torch.pow(torch.sum(torch.pow(diff, exponent=p), axis=2), exponent=1 / p)

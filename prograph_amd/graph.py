@@ -152,10 +152,25 @@ class KNNGraph:
 # pickles the DataFrame, `Neighbours` column of N tuples included (prograph/utils/save.py:5-39);
 # at N = 1M that is a million small arrays.  A graph is three flat arrays: they go into one .npz.
 # ----------------------------------------------------------------------------------------------
-def save_graphs(path, graphs):
+def fingerprint(tokens):
+    """64-bit fingerprint of a token matrix (shape + an order-sensitive checksum): what ties a graph side-car to the
+    data it was built from."""
+    t = np.ascontiguousarray(np.asarray(tokens)).astype(np.uint8, copy=False)
+    h = np.uint64(1469598103934665603)
+    with np.errstate(over="ignore"):
+        w = (np.arange(1, t.shape[1] + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))[None, :] if t.ndim == 2 and t.size else np.zeros((1, 0), np.uint64)
+        rows = (t.astype(np.uint64) * w).sum(axis=1) if t.size else np.zeros(0, np.uint64)
+        idx = np.arange(1, len(rows) + 1, dtype=np.uint64) * np.uint64(0xBF58476D1CE4E5B9)
+        h = h ^ np.uint64((rows * idx).sum()) ^ (np.uint64(t.shape[0]) << np.uint64(32)) ^ np.uint64(t.shape[1] if t.ndim == 2 else 0)
+    return int(h)
+
+
+def save_graphs(path, graphs, tokens_fingerprint=None):
     """{name: CSRGraph | KNNGraph} -> one .npz (arrays `<name>/indptr|indices|weights` or `<name>/idx|dist`
-    plus a small meta vector [kind, ncols, similarity, row0])."""
+    plus a small meta vector [kind, ncols, similarity, row0]); `__fingerprint__` = fingerprint of the token matrix."""
     out = {}
+    if tokens_fingerprint is not None:
+        out["__fingerprint__"] = np.array([tokens_fingerprint], dtype=np.uint64)
     for name, g in graphs.items():
         if isinstance(g, KNNGraph):
             out[f"{name}/idx"] = g.idx.cpu().numpy()
@@ -169,16 +184,31 @@ def save_graphs(path, graphs):
     np.savez(path, **out)
 
 
-def load_graphs(path, device=None):
-    """Inverse of save_graphs (no pickled objects inside: plain arrays, `allow_pickle=False`)."""
+def load_graphs(path, device=None, tokens_fingerprint=None):
+    """Inverse of save_graphs (no pickled objects inside: plain arrays, `allow_pickle=False`).  With
+    `tokens_fingerprint` a side-car written for other data (or by a version without fingerprints) yields nothing;
+    graphs whose arrays are not a well-formed CSR / kNN table over `ncols` columns are skipped (device kernels index
+    by these columns)."""
     device = _native.device() if device is None else device
     z = np.load(path, allow_pickle=False)
     graphs = {}
+    if tokens_fingerprint is not None:
+        if "__fingerprint__" not in z.files or int(z["__fingerprint__"][0]) != int(tokens_fingerprint):
+            return graphs
     for key in z.files:
         if not key.endswith("/meta"):
             continue
         name = key[:-5]
         kind, ncols, sim, row0 = (int(v) for v in z[key])
+        if kind == 1:
+            idx = z[f"{name}/idx"]
+            if idx.ndim != 2 or z[f"{name}/dist"].shape != idx.shape or (idx.size and (idx.min() < -1 or idx.max() >= ncols)):
+                continue
+        else:
+            ip, ix = z[f"{name}/indptr"], z[f"{name}/indices"]
+            if (ip.ndim != 1 or len(ip) < 1 or ip[0] != 0 or np.any(np.diff(ip) < 0) or int(ip[-1]) != len(ix)
+                    or len(z[f"{name}/weights"]) != len(ix) or (len(ix) and (ix.min() < 0 or ix.max() >= ncols))):
+                continue
         t = lambda a: torch.from_numpy(np.ascontiguousarray(z[f"{name}/{a}"])).to(device)
         if kind == 1:
             graphs[name] = KNNGraph(t("idx"), t("dist"), ncols, similarity=bool(sim), row0=row0)

@@ -79,7 +79,7 @@ class Prograph:
 
         if "Tokenized" not in self.graph:
             self.graph["Tokenized"] = list(self.tokenized)
-        if isinstance(file, str) and file.endswith(".pkl"):
+        if isinstance(file, str) and ext == "pkl":
             self._restore_graphs(os.path.splitext(file)[0] + ".graphs.npz")
         if "Neighbours" not in self.graph:
             self.graph["Neighbours"] = self.build_graph(eps=1, _keep="Neighbours")
@@ -467,8 +467,14 @@ class Prograph:
                 if idxs.dtype == bool:
                     idxs = np.nonzero(idxs)[0]
         if distance is minkowski and comp in _CMP_CODE and (k is None or k <= _native.MAX_K):
+            if output == "csr":
+                raise NotImplementedError("output='csr' (device-resident graphs) exists for the Hamming path only; "
+                                          "Minkowski graphs are returned as the reference's tuples")
             out = self._build_graph_minkowski(idxs, eps, k, similarity, representation, comp)
             if out is not None:
+                if store is not None and idxs is None:
+                    self.graph[store] = out       # (no device graph is kept: the consumers take the column path)
+                    self.csr_graphs.pop(store, None)
                 return out
         native = distance is hamming and (comp in _CMP_CODE) and (k is None or k <= _native.MAX_K_ROUNDS)
         planes = None
@@ -587,8 +593,8 @@ class Prograph:
         columns (the reference's tuple format, views into two host arrays per graph) into the frame."""
         if not os.path.exists(sidecar):
             return
-        from .graph import load_graphs
-        for name, g in load_graphs(sidecar).items():
+        from .graph import load_graphs, fingerprint
+        for name, g in load_graphs(sidecar, tokens_fingerprint=fingerprint(self.tokenized)).items():
             if name in self.graph or g.nrows != len(self.graph):
                 continue
             tuples = g.to_tuples()

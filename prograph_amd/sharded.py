@@ -37,35 +37,89 @@ def shard_rows(n, world):
 _COMMS = {}     # (world, rank, device index) -> RCCL communicator handle of this process
 
 
-def _comm(world, rank, dev, group=None):
-    """This rank's RCCL communicator (created once): rank 0 makes the id, torch.distributed's
-    object broadcast carries the 128 bytes - the only use of torch.distributed on the GPU data path."""
-    key = (world, rank, dev.index)
-    if key not in _COMMS:
-        box = [_native.comm_unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(box, src=0, group=group)
-        comm, err = None, None
+def _comm_init_guarded(world, rank, dev, id_bytes, timeout_s):
+    """`pg_comm_init` (ncclCommInitRank: a collective - it returns only when every rank has entered it) under a watchdog:
+    a peer that died before entering would leave this rank blocked inside RCCL's bootstrap for good, so after
+    `timeout_s` the process reports and exits non-zero (no re-exec, nothing to unwind: the thread is stuck in RCCL)."""
+    import os
+    import sys
+    import threading
+    box = {}
+
+    def run():
         try:
             with torch.cuda.device(dev):
-                comm = _native.comm_init(world, rank, box[0])
+                box["comm"] = _native.comm_init(world, rank, id_bytes)
+        except Exception as e:          # noqa: BLE001 - handed to the caller
+            box["err"] = e
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        print(f"[prograph_amd] rank {rank}: pg_comm_init did not return within {timeout_s:.0f} s "
+              "(a peer rank never entered it?); giving up", file=sys.stderr, flush=True)
+        os._exit(3)
+    if "err" in box:
+        raise box["err"]
+    return box["comm"]
+
+
+def _comm(world, rank, dev, group=None):
+    """This rank's RCCL communicator (created once): rank 0 makes the id, torch.distributed's
+    object broadcast carries the 128 bytes - the only use of torch.distributed on the GPU data path.
+    Returns False when the ranks agreed to gather through torch.distributed instead.
+    Every step that can fail on ONE rank only is followed by an agreement of all ranks before anybody enters
+    something collective: (1) can RCCL be bound at all (local check), (2) did rank 0 obtain an id, (3) did
+    ncclCommInitRank succeed everywhere.  The collective init itself runs under a timeout (PG_COMM_TIMEOUT, 120 s)."""
+    import os
+    import sys
+    key = (world, rank, dev.index)
+    if key in _COMMS:
+        return _COMMS[key]
+
+    def agree(flag):                    # True only when `flag` holds on every rank
+        if world == 1:
+            return bool(flag)
+        ok = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        return int(ok.item()) == 1
+
+    def fall_back(why):
+        print(f"[prograph_amd] rank {rank}: {why}; the shards are gathered with torch.distributed's RCCL all-gather instead",
+              file=sys.stderr, flush=True)
+        _COMMS[key] = False
+        return False
+
+    if not agree(_native.comm_available()):
+        if world == 1:
+            _native.comm_unique_id()    # one rank, nothing to fall back to: raise the library's own error
+        return fall_back("librccl.so cannot be bound on at least one rank")
+    box, err = [None], None
+    if rank == 0:
+        try:
+            box[0] = _native.comm_unique_id()
         except Exception as e:          # noqa: BLE001 - reported below, never silent
             err = e
-        if world > 1:
-            # every rank must take the same road: agree on "all communicators are up"
-            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-            if int(ok.item()) == 0:
-                if comm is not None:
-                    _native.comm_destroy(comm)
-                import sys
-                print(f"[prograph_amd] rank {rank}: pg_comm_init failed on at least one rank ({err!r}); "
-                      "the shards are gathered with torch.distributed's RCCL all-gather instead", file=sys.stderr, flush=True)
-                comm = False
-        elif comm is None:
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    if box[0] is None:
+        if world == 1:
             raise err
-        _COMMS[key] = comm
-    return _COMMS[key]
+        return fall_back(f"rank 0 could not create the communicator id ({err!r})")
+    comm = None
+    try:
+        comm = _comm_init_guarded(world, rank, dev, box[0], float(os.environ.get("PG_COMM_TIMEOUT", "120")))
+    except Exception as e:              # noqa: BLE001
+        err = e
+    if not agree(comm is not None):
+        if comm is not None:
+            _native.comm_destroy(comm)
+        if world == 1:
+            raise err
+        return fall_back(f"pg_comm_init failed on at least one rank ({err!r})")
+    _COMMS[key] = comm
+    return comm
 
 
 def allgather_tokens(local_tokens, n_total, group=None):
@@ -86,7 +140,8 @@ def allgather_tokens(local_tokens, n_total, group=None):
         padded[: local_tokens.shape[0]] = local_tokens
         local_tokens = padded
     if local_tokens.is_cuda and dist.get_backend(group) != "gloo":
-        comm = _comm(world, rank, local_tokens.device, group)
+        # (the C-ABI collective moves bytes: other token dtypes go through torch's all-gather of the same library)
+        comm = _comm(world, rank, local_tokens.device, group) if local_tokens.dtype == torch.uint8 else False
         if comm is not False:
             return _native.allgather_tokens(comm, local_tokens, world)[:n_total]
         # the C-ABI communicator could not be created (reported on stderr): the same collective through torch's RCCL

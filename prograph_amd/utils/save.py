@@ -22,11 +22,14 @@ def save(pgraph, name=None, ext=".pkl", directory=None, ignored_cols=["Tokenized
     print(f"Saving Graph to {os.path.basename(target)}")
     try:
         ignored = list(ignored_cols)
+        sidecar = os.path.splitext(target)[0] + ".graphs.npz"
         if graphs == "csr":
-            from ..graph import save_graphs
+            from ..graph import save_graphs, fingerprint
             live = {n: g for n in pgraph.csr_graphs if n in pgraph.graph and (g := pgraph._device_graph_any(n)) is not None}
-            save_graphs(os.path.splitext(target)[0] + ".graphs.npz", live)
+            save_graphs(sidecar, live, tokens_fingerprint=fingerprint(pgraph.tokenized))
             ignored += list(live)
+        elif os.path.exists(sidecar):
+            os.remove(sidecar)          # a side-car of an earlier graphs="csr" save would shadow this pickle's columns
         columns = [c for c in pgraph.graph.columns if c not in ignored]
         pgraph.graph[columns].to_pickle(target)
     except Exception as err:
