@@ -79,7 +79,8 @@ int pg_nchunks(int l, int bits) { return (pg_ngroups(l) * bits + 3) / 4; }
 int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunks(l, bits) * 16 + PG_AUX_BYTES) * pg_npad(n); }
 // launch-private device state of an all-pairs call: today the pass counter of the persistent waves (one word in a
 // 64-byte line of its own); sized by the row count so that later per-row state needs no ABI change
-int64_t pg_workspace_bytes(int64_t nrows) { (void)nrows; return 256; }
+// [0, 64) the pass counter, [64, 128) the probe's decision words (gates), [128, 128 + 8 * PG_PROBE_ROWS * PG_PROBE_WAVES) its counts
+int64_t pg_workspace_bytes(int64_t nrows) { (void)nrows; return 128 + 8 * 64 * 128; }
 
 }  // extern "C"
 
@@ -353,6 +354,85 @@ static void eps_interval(int cmp, double eps, u32 *lo, u32 *span) {
   if (h < l) { *lo = 0xFFFFFF00u; *span = 0; return; }
   *lo = (u32)l;
   *span = (u32)(h - l);
+}
+
+// ---------------------------------------------------------------------------------------
+// Data probe + decision (no host round trip): pg_probe_kernel counts, for PG_PROBE_ROWS sample rows of the launch, the
+// columns nearer than the kNN cap and the columns inside the eps interval; pg_decide_kernel turns them into the gate
+// words the alternative kernels of the launch test at their start (NsqParams::gate):
+//   gate[0]  kNN engine: 0 = MFMA engine, 1 = VALU engine.  Unclustered data (fewer than half of the sample rows have
+//            k + 1 columns below the cap: the signature filter never gets a useful bound, every distance is needed)
+//            runs ~8 % faster on the VALU engine's direct form (profiles/r03_engine_landscape.txt: random N = 200k)
+//   gate[1]  whole-square eps graph: 0 = every unordered pair once (symmetric slots), 1 = rectangular VALU sweep.
+//            Dense graphs (more than 4 % of all pairs match) pay more for the symmetric path's atomics and
+//            unsorted back parts than it saves (one cluster, eps <= 2: 39.6 vs 29.4 ms)
+// ---------------------------------------------------------------------------------------
+#define PG_PROBE_ROWS 64        // sample rows
+#define PG_PROBE_WAVES 128      // waves per sample row: every 8th column tile (PG_PROBE_STRIDE), one turn of four tiles each at N = 200k
+                                // (a turn = one L2 / Infinity-Cache round trip, ~2 us: 1 x 1 wave 206 us, 64 x 4 67 us, 64 x 32 22 us)
+#define PG_PROBE_MIN_N 65536    // launches below this are not probed: the probe (~20 us) would show, and the size rules hold
+// one workgroup: 16 threads per sample row (a quarter wave) sum the row's per-wave counts, the wave of a row then the
+// workgroup combine the verdicts
+__global__ __launch_bounds__(1024) void pg_decide_kernel(const u32 *counts, int nsample, int wavesPerRow, u32 need, long long ncols,
+                                                          int force, u32 *gate) {
+  __shared__ u32 sClustered[16];
+  __shared__ unsigned long long sEps[16];
+  const int tid = threadIdx.x, s = tid >> 4, sub = tid & 15;
+  u32 nearS = 0, epsS = 0;
+  if (s < nsample)
+    for (int w = sub; w < wavesPerRow; w += 16) {
+      nearS += counts[2 * (s * wavesPerRow + w)];
+      epsS += counts[2 * (s * wavesPerRow + w) + 1];
+    }
+  for (int o = 8; o > 0; o >>= 1) {
+    nearS += (u32)__shfl_xor((int)nearS, o);
+    epsS += (u32)__shfl_xor((int)epsS, o);
+  }
+  // (counts are over every PG_PROBE_STRIDE-th tile)
+  u32 clustered = (sub == 0 && s < nsample && nearS * PG_PROBE_STRIDE >= need) ? 1u : 0u;
+  unsigned long long eps = (sub == 0 && s < nsample) ? (unsigned long long)epsS * PG_PROBE_STRIDE : 0ull;
+  for (int o = 32; o > 0; o >>= 1) {
+    clustered += (u32)__shfl_xor((int)clustered, o);
+    eps += (unsigned long long)__shfl_xor((long long)eps, o);
+  }
+  if ((tid & 63) == 0) { sClustered[tid >> 6] = clustered; sEps[tid >> 6] = eps; }
+  __syncthreads();
+  if (tid == 0) {
+    clustered = 0; eps = 0;
+    for (int i = 0; i < 16; ++i) { clustered += sClustered[i]; eps += sEps[i]; }
+    gate[0] = force >= 0 ? (u32)(force & 1) : (2u * clustered >= (u32)nsample ? 0u : 1u);
+    gate[1] = force >= 0 ? (u32)((force >> 1) & 1) : (eps * 25ull > (unsigned long long)nsample * (unsigned long long)ncols ? 1u : 0u);
+  }
+}
+typedef int (*probe_fn)(int, const ProbeParams &, hipStream_t);
+static const probe_fn kProbe[8] = {pg_launch_probe_g1, pg_launch_probe_g2, pg_launch_probe_g3, pg_launch_probe_g4,
+                                   pg_launch_probe_g5, pg_launch_probe_g6, pg_launch_probe_g7, pg_launch_probe_g8};
+// PG_PROBE=0: no probe (the size rules alone); PG_GATE_FORCE=<bits>: the decision is forced (tests): bit 0 gate[0], bit 1 gate[1]
+static bool probe_enabled() {
+  const char *e = getenv("PG_PROBE");
+  return !(e && atoi(e) == 0) && !getenv("PG_ENGINE") && !getenv("PG_ENGINE_MIN_ROWS");
+}
+// zeroes and fills workspace[64, ...): returns the gate words through *gate
+static int run_probe(const NsqParams &e, int l, int bits, u32 near, u32 lo, u32 span, u32 need, void *workspace, hipStream_t s,
+                     const u32 **gate) {
+  if (!workspace) return fail(PG_E_BADARG, "workspace required (pg_workspace_bytes)");
+  u32 *gates = (u32 *)((char *)workspace + 64), *counts = (u32 *)((char *)workspace + 128);
+  static_assert(128 + 8 * PG_PROBE_ROWS * PG_PROBE_WAVES <= 128 + 8 * 64 * 128, "pg_workspace_bytes");
+  ProbeParams pp;
+  pp.rowPlanes = e.rowPlanes; pp.colPlanes = e.colPlanes; pp.rowNpad = e.rowNpad; pp.colNpad = e.colNpad;
+  pp.row0 = e.row0; pp.nrows = e.nrows; pp.ncols = e.ncols;
+  pp.nsample = e.nrows < PG_PROBE_ROWS ? (int)e.nrows : PG_PROBE_ROWS;
+  pp.wavesPerRow = PG_PROBE_WAVES;
+  if (const char *es = getenv("PG_PROBE_S")) { if (atoi(es) > 0 && atoi(es) <= PG_PROBE_ROWS) pp.nsample = atoi(es); }   // (experiments)
+  if (const char *ew = getenv("PG_PROBE_W")) { if (atoi(ew) > 0 && atoi(ew) <= PG_PROBE_WAVES) pp.wavesPerRow = atoi(ew); }
+  pp.near = near; pp.lo = lo; pp.span = span; pp.counts = counts;
+  if (int rc = launched(kProbe[pg_ngroups(l) - 1](bits, pp, s), "pg_probe_kernel")) return rc;
+  const int force = getenv("PG_GATE_FORCE") ? atoi(getenv("PG_GATE_FORCE")) : -1;
+  // (counts of a short sample: pg_decide_kernel reads counts[nsample + s] - same layout as the probe wrote)
+  pg_decide_kernel<<<dim3(1), dim3(1024), 0, s>>>(counts, pp.nsample, pp.wavesPerRow, need, e.ncols, force, gates);   // (PG_PROBE_ROWS <= 64)
+  if (int rc = launched((int)hipGetLastError(), "pg_decide_kernel")) return rc;
+  *gate = gates;
+  return 0;
 }
 
 typedef int (*nsq_fn)(int, int, const NsqParams &, int, hipStream_t);
@@ -650,6 +730,19 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
   hipError_t e = hipMemsetAsync(counts_lo, 0, (size_t)n * sizeof(uint32_t), (hipStream_t)stream);
   if (e != hipSuccess) return hipfail(e, "hipMemsetAsync");
   int grid = 0;
+  // Large graphs: the data decide (probe above) between this path and a plain rectangular sweep on the VALU engine,
+  // which writes the same slots (every match at the front of its row, counts_lo stays zero): dense graphs.
+  if (probe_enabled() && n >= PG_PROBE_MIN_N) {
+    const u32 *gate = nullptr;
+    if (int rc = run_probe(p, l, bits, 0u, p.lo, p.span, 1u, workspace, (hipStream_t)stream, &gate)) return rc;
+    NsqParams r = p;
+    r.countsLo = nullptr;
+    r.gate = gate + 1; r.gateWant = 1u;
+    int rgrid = 0;
+    if (int rc = plan_rows(n, &r, &rgrid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS, bits), 16.0 * pg_nchunks(l, bits))) return rc;
+    if (int rc = launched(kNsq[pg_ngroups(l) - 1](PG_MODE_EPS, bits, r, rgrid, (hipStream_t)stream), "pg_nsq_kernel(eps, gated)")) return rc;
+    p.gate = gate + 1; p.gateWant = 0u;
+  }
   // Rows near the top sweep almost everything, rows near the bottom almost nothing; workgroups are
   // dispatched in row order, i.e. longest first, which balances by itself once there are a few
   // waves per resident slot.  Measured (tools/eps_sym_probe.py): 8 rows per wave at N = 50k, 16 at
@@ -760,11 +853,28 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   // pg_mm.h: 10 with the 54-bit signature (L > 32) - unrelated pairs below it are one in 3e6, kNN time is flat from
   // 7 to 12 on every shape tried (tools/guess_sweep.py) and rows whose k-th distance reaches 9 keep their cap;
   // 7 where the signature is the 32 plane-0 bits of a single group (L <= 32: one in 4e3 at 7, one in 400 at 10)
-  p.knnGuess = getenv("PG_KNN_GUESS") ? (u32)atoi(getenv("PG_KNN_GUESS")) : (use_mm_engine(nrows) ? (l > 32 ? 10u : 7u) : 8u);
+  const bool mm = use_mm_engine(nrows);
+  const u32 guessMm = l > 32 ? 10u : 7u, guessValu = 8u;
+  p.knnGuess = getenv("PG_KNN_GUESS") ? (u32)atoi(getenv("PG_KNN_GUESS")) : (mm ? guessMm : guessValu);
   if (p.filter == 0) p.knnGuess = 0;                       // no stage 1, nothing to cap
   p.knnIdx = idx_out; p.knnDist = dist_out;
   int grid = 0;
-  if (use_mm_engine(nrows)) {
+  auto launch_valu = [&](NsqParams &q) -> int {
+    int g = 0;
+    if (int rc = plan_rows(nrows, &q, &g, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits), 16.0 * pg_nchunks(l, bits), PG_RB_KNN)) return rc;
+    return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_KNN, bits, q, g, (hipStream_t)stream), "pg_nsq_kernel(knn)");
+  };
+  if (mm) {
+    // Large launches: the data decide between the engines (probe above): unclustered data -> the VALU engine
+    if (probe_enabled() && ncols >= PG_PROBE_MIN_N && nrows >= PG_PROBE_MIN_N / 2 && p.filter != 0 && !getenv("PG_KNN_GUESS")) {
+      const u32 *gate = nullptr;
+      if (int rc = run_probe(p, l, bits, p.knnGuess, 1u, 0u, (u32)(first + k), workspace, (hipStream_t)stream, &gate)) return rc;
+      NsqParams v = p;
+      v.knnGuess = guessValu;
+      v.gate = gate; v.gateWant = 1u;
+      if (int rc = launch_valu(v)) return rc;
+      p.gate = gate; p.gateWant = 0u;
+    }
     // short lists (the usual k): the instance that inserts a whole batch of candidates at once (pg_mm.h, KL).
     // PG_MM_SHORT=0 keeps the 64-lane lists (A/B runs)
     const bool shortList = first == 1 && k + 1 <= PG_MM_KL && !floor_keys && !last_keys &&
@@ -779,8 +889,7 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     return launched(kMm[pg_ngroups(l) - 1](two ? PG_MODE_KNN_SHORT2 : (shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN), bits, p, grid,
                                            (hipStream_t)stream), "pg_mm_kernel(knn)");
   }
-  if (int rc = plan_rows(nrows, &p, &grid, nsq_occupancy(pg_ngroups(l), PG_MODE_KNN, bits), 16.0 * pg_nchunks(l, bits), PG_RB_KNN)) return rc;
-  return launched(kNsq[pg_ngroups(l) - 1](PG_MODE_KNN, bits, p, grid, (hipStream_t)stream), "pg_nsq_kernel(knn)");
+  return launch_valu(p);
 }
 
 int pg_knn_hamming(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,

@@ -291,6 +291,11 @@ struct NsqParams {
   long long mmPasses, mmGridWaves;   // pg_mm.h: passes in all; waves in the grid (wave w starts with pass w, then takes
   unsigned *mmPassCounter;           // mmGridWaves + atomicAdd(counter) until none is left); the counter starts at 0
   int mmDenseL1, mmDenseL2, mmDirectRun;   // pg_mm.h: density rules of the filter hierarchy
+  // data-driven choice between engines / paths WITHOUT a host round trip (pg_api.hip: probe): when `gate` is not
+  // NULL the kernel runs only if *gate == gateWant (a device word the probe's decision kernel wrote on the same
+  // stream); the alternatives are all launched, all but one leave at once
+  const u32 *gate;
+  u32 gateWant;
   int filter;   // 1 = plane-0 lower-bound filter allowed (adaptive per tile), 0 = always direct
   u32 knnGuess; // kNN: optimistic cap on the stage-1 bound until a row's list is full (0 = off), see pg_nsq.h
   // eps
@@ -308,6 +313,17 @@ struct NsqParams {
   u32 *lastKeys;
   int *knnIdx;
   unsigned char *knnDist;
+};
+
+// Probe of the data in front of an all-pairs launch (pg_api.hip): exact distances of `nsample` evenly spaced rows of the
+// launch against all columns, counted per sample row: columns nearer than `near` and columns inside the eps interval.
+#define PG_PROBE_STRIDE 8   // the probe looks at every 8th tile of 64 columns
+struct ProbeParams {
+  const uint4 *rowPlanes, *colPlanes;
+  long long rowNpad, colNpad, row0, nrows, ncols;
+  int nsample, wavesPerRow;
+  u32 near, lo, span;
+  u32 *counts;   // [nsample * wavesPerRow][2]: per wave its near count and its eps count
 };
 
 struct DenseParams {
@@ -337,7 +353,8 @@ void pg_set_error(const char *msg);   // thread-local message behind pg_last_err
   int pg_occ_nsq_g##G(int mode, int bits); /* resident workgroups per CU of that instance */ \
   int pg_launch_mm_g##G(int mode, int bits, const NsqParams &p, int grid, hipStream_t s); /* MFMA stage 1 (pg_mm.h) */ \
   int pg_launch_dense_g##G(int bits, const DenseParams &p, hipStream_t s);                    \
-  int pg_launch_compact_g##G(int bits, const CompactParams &p, hipStream_t s);
+  int pg_launch_compact_g##G(int bits, const CompactParams &p, hipStream_t s);                \
+  int pg_launch_probe_g##G(int bits, const ProbeParams &p, hipStream_t s);
 PG_DECL_G(1) PG_DECL_G(2) PG_DECL_G(3) PG_DECL_G(4) PG_DECL_G(5) PG_DECL_G(6) PG_DECL_G(7) PG_DECL_G(8)
 int pg_launch_nsq_bag(const NsqParams &p, int grid, hipStream_t s);   // pg_lev.hip
 int pg_launch_nsq_bag_sym(const NsqParams &p, int grid, hipStream_t s);

@@ -53,6 +53,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
   const long long wr0 = gw * p.rowsPerWave;
   if (wr0 >= p.nrows) return;   // whole wave leaves; no workgroup barrier is used below
+  if (p.gate && __builtin_nontemporal_load(p.gate) != p.gateWant) return;   // the probe chose another engine / path
   const long long wr1 = (wr0 + p.rowsPerWave < p.nrows) ? wr0 + p.rowsPerWave : p.nrows;
   const int ntiles = (int)((p.ncols + 64 * C - 1) / (64 * C));   // ncols < 2^31
   const uint4 *__restrict__ colp = p.colPlanes;
@@ -626,6 +627,56 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_dense_kernel(const DensePara
       OutT *o = &out[(r0 + rr) * p.ldo + col];
       *o = p.accumulate ? (OutT)(*o + (OutT)d) : (OutT)d;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Data probe in front of a large all-pairs launch: exact distances of a few sample rows against all columns, counted
+// (see ProbeParams).  Grid: nsample * wavesPerRow waves; wave w of a sample row takes every wavesPerRow-th tile of 64
+// columns.  ~1e-3 of the launch's pair count.
+// ---------------------------------------------------------------------------------------
+template <int G, int B>
+__global__ __launch_bounds__(PG_WG_THREADS) void pg_probe_kernel(const ProbeParams p) {
+  constexpr int Q = Rec<G, B>::Q;
+  const int lane = threadIdx.x & 63;
+  const long long gw = (long long)blockIdx.x * PG_WG_WAVES + (threadIdx.x >> 6);
+  const int s = (int)(gw / p.wavesPerRow), part = (int)(gw % p.wavesPerRow);
+  if (s >= p.nsample) return;
+  const long long row = p.row0 + (p.nrows * (2ll * s + 1)) / (2ll * p.nsample);      // evenly spaced over the launch's rows
+  uint4 r[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) r[q] = p.rowPlanes[(long long)q * p.rowNpad + row];
+  u32 nearCnt = 0, epsCnt = 0;
+  // every PG_PROBE_STRIDE-th tile of 64 columns (offset by the sample row: different rows, different tiles): a
+  // sample of the columns is enough for the two yes/no questions asked, and S full sweeps would cost S x the matrix
+  // in cache traffic.  Tile index below = index among the sampled tiles.
+  const long long ntiles = ((p.ncols + 63) / 64 - (s % PG_PROBE_STRIDE) + PG_PROBE_STRIDE - 1) / PG_PROBE_STRIDE;
+  // four tiles per turn: their loads are in flight together (a wave's turns are a dependent chain of L2 round trips)
+  constexpr int T = 4;
+  for (long long t = part; t < ntiles; t += (long long)T * p.wavesPerRow) {
+    uint4 c[T][Q];
+    long long col[T];
+    bool in[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      const long long ti = t + (long long)i * p.wavesPerRow;
+      in[i] = ti < ntiles;
+      col[i] = ((in[i] ? ti : t) * PG_PROBE_STRIDE + (s % PG_PROBE_STRIDE)) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) c[i][q] = p.colPlanes[(long long)q * p.colNpad + col[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      const u32 d = mismatch<G, B>(r, c[i]);
+      const bool ok = in[i] && col[i] < p.ncols;
+      nearCnt += (u32)__popcll(__builtin_amdgcn_ballot_w64(ok && d < p.near));
+      epsCnt += (u32)__popcll(__builtin_amdgcn_ballot_w64(ok && (d - p.lo) <= p.span));
+    }
+  }
+  // one slot per wave, plain stores (atomics of thousands of waves onto a few cache lines serialise: ~88 per us and line)
+  if (lane == 0) {
+    p.counts[2 * gw] = nearCnt;
+    p.counts[2 * gw + 1] = epsCnt;
   }
 }
 

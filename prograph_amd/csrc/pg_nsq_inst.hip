@@ -100,6 +100,17 @@ int PG_CAT(pg_launch_dense_g, PG_G)(int bits, const DenseParams &p, hipStream_t 
   return bits == 5 ? launch_dense<5>(p, s) : launch_dense<8>(p, s);
 }
 
+int PG_CAT(pg_launch_probe_g, PG_G)(int bits, const ProbeParams &p, hipStream_t s) {
+  const unsigned grid = (unsigned)(((long long)p.nsample * p.wavesPerRow + PG_WG_WAVES - 1) / PG_WG_WAVES);
+  if (bits == 5) {
+    pg_probe_kernel<PG_G, 5><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+  } else {
+    if constexpr (Cols<8>::kBuilt) pg_probe_kernel<PG_G, 8><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+    else return (int)hipErrorInvalidValue;
+  }
+  return (int)hipGetLastError();
+}
+
 int PG_CAT(pg_launch_compact_g, PG_G)(int bits, const CompactParams &p, hipStream_t s) {
   const unsigned grid = (unsigned)((p.e.nrows + PG_WG_WAVES - 1) / PG_WG_WAVES);
   if (bits == 5) {

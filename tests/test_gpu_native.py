@@ -242,8 +242,8 @@ def test_device_tokenisation_matches_the_reference(nat):
     for j, ch in enumerate(aa, start=1):
         table[ord(ch)] = j
     def view(seqs):
-        arr = np.array(seqs, dtype="bytes").reshape(-1)
-        return np.frombuffer(arr.tobytes(), dtype=np.uint8).reshape(len(arr), max(arr.dtype.itemsize, 1))
+        arr = np.ascontiguousarray(np.array(seqs, dtype="bytes").reshape(-1))
+        return arr.view(np.uint8).reshape(len(arr), max(arr.dtype.itemsize, 1)) if arr.dtype.itemsize else np.zeros((len(arr), 1), np.uint8)
     kats = [(["ACA"], [[1, 2, 1]]), (["ACA", "ACC"], [[1, 2, 1], [1, 2, 2]]),
             (["ACCCACAAA", "ACAA"], [[1, 2, 2, 2, 1, 2, 1, 1, 1], [1, 2, 1, 1, 0, 0, 0, 0, 0]])]
     for seqs, want in kats:
@@ -996,6 +996,33 @@ def test_second_device_when_present(nat, monkeypatch):
             idx, dist = nat.knn_graph(p, p, 8)
             res.append((idx.cpu(), dist.cpu()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@one_engine
+@pytest.mark.parametrize("force", ["0", "1", "2", "3"])
+def test_probe_gated_alternatives_agree(nat, monkeypatch, force):
+    """Large launches carry two alternatives (MFMA / VALU engine for kNN; symmetric / rectangular sweep for the whole
+    eps graph) and a device-side probe decides which one runs (pg_api.hip: run_probe, NsqParams::gate).  Forcing the
+    decision either way must give the identical result - and the unforced decision must be one of them."""
+    from prograph_amd import synth
+    monkeypatch.delenv("PG_GATE_FORCE", raising=False)
+    tok = synth.clustered_tokens(70_000, 64, seed=21, members=128)       # (above PG_PROBE_MIN_N)
+    p = _planes(nat, tok, 5)
+    ref_k = nat.knn_graph(p, p, 12)
+    ref_e = nat.eps_graph(p, p, nat.CMP_LE, 2)
+    monkeypatch.setenv("PG_GATE_FORCE", force)
+    got_k = nat.knn_graph(p, p, 12)
+    got_e = nat.eps_graph(p, p, nat.CMP_LE, 2)
+    assert torch.equal(got_k[0], ref_k[0]) and torch.equal(got_k[1], ref_k[1])
+    assert all(torch.equal(a, b) for a, b in zip(got_e, ref_e))
+    # unclustered data: the probe sends kNN to the VALU engine; both engines agree on it anyway
+    monkeypatch.delenv("PG_GATE_FORCE", raising=False)
+    rnd = np.random.RandomState(8).randint(1, 21, size=(66_000, 64)).astype(np.uint8)
+    pr = _planes(nat, rnd, 5)
+    auto = nat.knn_graph(pr, pr, 5)
+    monkeypatch.setenv("PG_GATE_FORCE", "0")
+    mfma = nat.knn_graph(pr, pr, 5)
+    assert torch.equal(auto[0], mfma[0]) and torch.equal(auto[1], mfma[1])
 
 
 @one_engine
