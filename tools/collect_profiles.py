@@ -31,6 +31,9 @@ for wl in wls:
         "wait_any_frac_of_wave_cycles": (summ["counters"].get("SQ_WAIT_ANY", 0) / summ["counters"]["SQ_WAVE_CYCLES"]) if summ["counters"].get("SQ_WAVE_CYCLES") else None,
         "clock_ghz": summ.get("clock_ghz"),
         "l2_hit_rate": summ.get("l2_hit_rate"),
+        "ta_busy_frac": summ.get("ta_busy_frac"),
+        "valu_busy_frac_of_simd_cycles": summ.get("valu_busy_frac_of_simd_cycles"),
+        "mfma_pipe_busy_frac": summ.get("mfma_pipe_busy_frac"),
         "source": f"profiles/{tag}_{wl}_rocprof_summary.json",
         "note": summ.get("hbm_note"),
     }

@@ -78,6 +78,12 @@ if "per_kernel_counters" in res:
     steps_profiled = 4
     res["valu_wave_instr_per_step_all_kernels"] = sum(v["SQ_INSTS_VALU"]["mean"] * v["SQ_INSTS_VALU"]["launches"]
                                                       for v in res["per_kernel_counters"].values() if "SQ_INSTS_VALU" in v) / steps_profiled
+if "TA_TA_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c:
+    # busy cycles summed over the 256 texture-address units (one per CU) / (256 x kernel cycles): the vector-memory path
+    res["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / (256.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+    # SQ_ACTIVE_INST_VALU counts quad-cycles; 1024 SIMDs x kernel cycles available
+    res["valu_busy_frac_of_simd_cycles"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
 if "TCC_HIT_sum" in c:
     res["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
 print(json.dumps(res, indent=1))
