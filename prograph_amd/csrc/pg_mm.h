@@ -650,8 +650,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           av7 = pg_or16(d1);                                                                       \
           found = __builtin_amdgcn_ballot_w64((av0 | av1 | av2 | av3 | av4 | av5 | av6 | av7) < 0) != 0; \
         }                                                                                          \
-        PG_ST(0, 1);                                                                               \
-        PG_ST(9, resweep);                                                                         \
       }
       // (no branch around a load statement: where two paths with different statements meet, the compiler copies
       //  ring registers - while their loads are still out.  So the prefetch is unconditional; at the last super-tile
@@ -1026,6 +1024,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         PG_T0(ts0);
         const int rc = scan(S, send < nextCk ? send : nextCk, send - 1);
         PG_T1(16, ts0);
+        PG_ST(0, S - Sin + (rc ? 1 : 0));                   // (counted here: nothing but the loop's own state lives in scan())
+        PG_ST(9, resweep ? S - Sin + (rc ? 1 : 0) : 0);
         if (S != Sin) drun = 0;                             // a clean stretch ends a series of dense runs
         if (rc == 0) continue;
         if (rc == 1) {                                      // candidates queued, the MFMA form goes on

@@ -88,3 +88,14 @@ def test_signature_helpers_on_the_host():
     subprocess.check_call(["make", "-s", "-C", capi, "_build/sig_check"])
     out = subprocess.run([os.path.join(capi, "_build", "sig_check")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "signature helpers OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_fragment_ring_rule_holds_in_the_generated_isa():
+    """pg_mm.h loads its column fragments with inline assembly the compiler cannot see through; its RULE - nothing
+    touches a ring register between such a load and the wait that covers it - is checked on the generated ISA
+    (tools/check_ring_asm.py; here for the cfg3 group count, every MFMA-engine instance of it: eps, symmetric eps,
+    kNN with 64-lane lists, with short lists, with two row blocks; 5 and 8 bit planes)."""
+    import subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "..", "tools", "check_ring_asm.py"), "2"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "RULE violations: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

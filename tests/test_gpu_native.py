@@ -152,8 +152,9 @@ def test_dense_vs_oracle_all_q(nat):
             assert np.array_equal(out.cpu().numpy(), ref), (L, bits)
 
 
-def test_engine_vs_oracle_all_q(nat):
-    """eps + kNN engines against the oracle for every group count G=1..8 (L up to 255)."""
+def test_engine_vs_oracle_all_q(nat, engine, monkeypatch):
+    """eps + kNN engines against the oracle for every group count G=1..8 (L up to 255); on the MFMA engine the kNN
+    instance with two row blocks per pass (64 rows; chosen by itself only from ~157 000 rows on) is forced as well."""
     from oracle import prograph_oracle as O
     from prograph_amd import synth
     for L in [5, 16, 24, 40, 50, 64, 70, 90, 100, 128, 129, 150, 192, 200, 230, 255]:
@@ -167,6 +168,11 @@ def test_engine_vs_oracle_all_q(nat):
             assert np.array_equal(ip, ref_e[0]) and np.array_equal(ix, ref_e[1]) and np.array_equal(w, ref_e[2]), (L, bits)
             kidx, kd = nat.knn_graph(p, p, 7)
             assert np.array_equal(kidx.cpu().numpy(), ref_k[0]) and np.array_equal(kd.cpu().numpy(), ref_k[1]), (L, bits)
+            if engine == "mfma":
+                monkeypatch.setenv("PG_MM_R", "2")
+                kidx, kd = nat.knn_graph(p, p, 7)
+                monkeypatch.delenv("PG_MM_R")
+                assert np.array_equal(kidx.cpu().numpy(), ref_k[0]) and np.array_equal(kd.cpu().numpy(), ref_k[1]), (L, bits, "R=2")
 
 
 def test_knn_edge_cases(nat):
@@ -576,15 +582,19 @@ def test_eps_symmetric_path_matches_rectangular(nat, monkeypatch, sym):
     assert np.array_equal(ip, rip) and np.array_equal(ix, rix) and np.array_equal(w, rw)
 
 
-@pytest.mark.parametrize("guess", ["0", "3", "8", "40"])
+@pytest.mark.parametrize("guess", ["0", "3", "8", "40", "8/R2"])
 def test_knn_optimistic_cap_is_exact(nat, monkeypatch, guess):
     """PG_KNN_GUESS (the optimistic stage-1 cap of the kNN engine) never changes results: rows that
     settle below the cap, rows that lose it at the first checkpoint (no near column: random rows),
     rows that lose it at the second (near columns, but fewer than k + 1 below the cap), the second
     sweep of the early tiles with ties decided by full keys and duplicates skipped, continuation
-    rounds (k > 63) and row windows.  0 switches the mechanism off."""
+    rounds (k > 63) and row windows.  0 switches the mechanism off.  "8/R2": the same on the MFMA engine's 64-row
+    instance (two row blocks per pass; no effect on the VALU engine)."""
     from oracle import c_oracle as C
     from prograph_amd import synth
+    if guess.endswith("/R2"):
+        guess = guess[:-3]
+        monkeypatch.setenv("PG_MM_R", "2")
     monkeypatch.setenv("PG_KNN_GUESS", guess)
     rng = np.random.RandomState(11)
     clustered = synth.clustered_tokens(9000, 64, seed=3, members=128)
