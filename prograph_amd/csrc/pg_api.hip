@@ -362,7 +362,9 @@ static void eps_interval(int cmp, double eps, u32 *lo, u32 *span) {
 // words the alternative kernels of the launch test at their start (NsqParams::gate):
 //   gate[0]  kNN engine: 0 = MFMA engine, 1 = VALU engine.  Unclustered data (fewer than half of the sample rows have
 //            k + 1 columns below the cap: the signature filter never gets a useful bound, every distance is needed)
-//            runs ~8 % faster on the VALU engine's direct form (profiles/r03_engine_landscape.txt: random N = 200k)
+//            runs ~8 % faster on the VALU engine's direct form (profiles/r03_engine_landscape.txt: random N = 200k);
+//            2 = MFMA engine with 32-row passes although 64-row passes were planned: ONE cluster (more than half of
+//            all pairs below the cap) lives in the folded form, where the finer pass granularity wins (11.7 vs 12.5 ms)
 //   gate[1]  whole-square eps graph: 0 = every unordered pair once (symmetric slots), 1 = rectangular VALU sweep.
 //            Dense graphs (more than 4 % of all pairs match) pay more for the symmetric path's atomics and
 //            unsorted back parts than it saves (one cluster, eps <= 2: 39.6 vs 29.4 ms)
@@ -376,7 +378,7 @@ static void eps_interval(int cmp, double eps, u32 *lo, u32 *span) {
 __global__ __launch_bounds__(1024) void pg_decide_kernel(const u32 *counts, int nsample, int wavesPerRow, u32 need, long long ncols,
                                                           int force, u32 *gate) {
   __shared__ u32 sClustered[16];
-  __shared__ unsigned long long sEps[16];
+  __shared__ unsigned long long sEps[16], sNear[16];
   const int tid = threadIdx.x, s = tid >> 4, sub = tid & 15;
   u32 nearS = 0, epsS = 0;
   if (s < nsample)
@@ -391,16 +393,19 @@ __global__ __launch_bounds__(1024) void pg_decide_kernel(const u32 *counts, int 
   // (counts are over every PG_PROBE_STRIDE-th tile)
   u32 clustered = (sub == 0 && s < nsample && nearS * PG_PROBE_STRIDE >= need) ? 1u : 0u;
   unsigned long long eps = (sub == 0 && s < nsample) ? (unsigned long long)epsS * PG_PROBE_STRIDE : 0ull;
+  unsigned long long nearAll = (sub == 0 && s < nsample) ? (unsigned long long)nearS * PG_PROBE_STRIDE : 0ull;
   for (int o = 32; o > 0; o >>= 1) {
     clustered += (u32)__shfl_xor((int)clustered, o);
     eps += (unsigned long long)__shfl_xor((long long)eps, o);
+    nearAll += (unsigned long long)__shfl_xor((long long)nearAll, o);
   }
-  if ((tid & 63) == 0) { sClustered[tid >> 6] = clustered; sEps[tid >> 6] = eps; }
+  if ((tid & 63) == 0) { sClustered[tid >> 6] = clustered; sEps[tid >> 6] = eps; sNear[tid >> 6] = nearAll; }
   __syncthreads();
   if (tid == 0) {
-    clustered = 0; eps = 0;
-    for (int i = 0; i < 16; ++i) { clustered += sClustered[i]; eps += sEps[i]; }
-    gate[0] = force >= 0 ? (u32)(force & 1) : (2u * clustered >= (u32)nsample ? 0u : 1u);
+    clustered = 0; eps = 0; nearAll = 0;
+    for (int i = 0; i < 16; ++i) { clustered += sClustered[i]; eps += sEps[i]; nearAll += sNear[i]; }
+    const bool oneCluster = 2ull * nearAll > (unsigned long long)nsample * (unsigned long long)ncols;
+    gate[0] = force >= 0 ? (u32)(force & 1) + ((force & 4) ? 2u : 0u) : (2u * clustered >= (u32)nsample ? (oneCluster ? 2u : 0u) : 1u);
     gate[1] = force >= 0 ? (u32)((force >> 1) & 1) : (eps * 25ull > (unsigned long long)nsample * (unsigned long long)ncols ? 1u : 0u);
   }
 }
@@ -687,7 +692,7 @@ static void plan_mm(int64_t nrows, NsqParams *p, int *grid, int rb = PG_MM_RB) {
 static int pass_counter(NsqParams *p, void *workspace, hipStream_t s) {
   if (!workspace) return fail(PG_E_BADARG, "workspace required (pg_workspace_bytes)");
   unsigned *c = (unsigned *)workspace;
-  const hipError_t e = hipMemsetAsync(c, 0, 64, s);
+  const hipError_t e = hipMemsetAsync(c, 0, 64, s);        // (two counters: words 0 and 8 - a launch's gated alternative has its own)
   if (e != hipSuccess) return hipfail(e, "workspace: hipMemsetAsync");
   p->mmPassCounter = c;
   return 0;
@@ -886,6 +891,15 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     if (const char *e = getenv("PG_MM_R")) two = shortList && atoi(e) == 2;
     plan_mm(nrows, &p, &grid, two ? 2 * PG_MM_RB : PG_MM_RB);
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
+    if (two && p.gate && !getenv("PG_MM_R")) {
+      // the probe may say "one cluster" (gate 2): the same engine with 32-row passes, launched as a third alternative
+      NsqParams q = p;
+      int qgrid = 0;
+      plan_mm(nrows, &q, &qgrid, PG_MM_RB);
+      q.mmPassCounter = p.mmPassCounter + 8;
+      q.gateWant = 2u;
+      if (int rc = launched(kMm[pg_ngroups(l) - 1](PG_MODE_KNN_SHORT, bits, q, qgrid, (hipStream_t)stream), "pg_mm_kernel(knn, 32-row passes, gated)")) return rc;
+    }
     return launched(kMm[pg_ngroups(l) - 1](two ? PG_MODE_KNN_SHORT2 : (shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN), bits, p, grid,
                                            (hipStream_t)stream), "pg_mm_kernel(knn)");
   }

@@ -1009,14 +1009,15 @@ def test_second_device_when_present(nat, monkeypatch):
 
 
 @one_engine
-@pytest.mark.parametrize("force", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("force", ["0", "1", "2", "3", "4"])
 def test_probe_gated_alternatives_agree(nat, monkeypatch, force):
     """Large launches carry two alternatives (MFMA / VALU engine for kNN; symmetric / rectangular sweep for the whole
     eps graph) and a device-side probe decides which one runs (pg_api.hip: run_probe, NsqParams::gate).  Forcing the
     decision either way must give the identical result - and the unforced decision must be one of them."""
     from prograph_amd import synth
     monkeypatch.delenv("PG_GATE_FORCE", raising=False)
-    tok = synth.clustered_tokens(70_000, 64, seed=21, members=128)       # (above PG_PROBE_MIN_N)
+    # (above PG_PROBE_MIN_N; force 4 = "one cluster": the 32-row instance where 64-row passes were planned - from ~157k rows)
+    tok = synth.clustered_tokens(160_000 if force == "4" else 70_000, 64, seed=21, members=128)
     p = _planes(nat, tok, 5)
     ref_k = nat.knn_graph(p, p, 12)
     ref_e = nat.eps_graph(p, p, nat.CMP_LE, 2)

@@ -1,5 +1,6 @@
-"""What the library picks by itself (engine, eps path: size rules + the device-side data probe) on the seven shapes of
-tools/mm_probe.py, to set beside that tool's forced combinations (profiles/r03_engine_landscape.txt)."""
+"""What the library picks by itself (engine, eps path: size rules + the device-side data probe) on seven shapes, timed
+beside every forced combination in the same process (profiles/r03_engine_landscape.txt): auto/best is the cost of the
+library's own choice, the probe and the gated launches included."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -33,6 +34,22 @@ for name, tok in cases:
         nat._check(L_.pg_eps_slots_sym(nat._ptr(p.buf), p.npad, p.n, p.g * 32, p.bits, nat.CMP_LE, 2.0, cap, nat._ptr(si), nat._ptr(sw),
                                        nat._ptr(cnt), nat._ptr(cl), nat._ptr(nat.workspace(N, dev)), nat._stream()), "sym")
     use_sym = N >= 32768          # _native.eps_graph's rule for the entry point
-    te = timeit(sym) if use_sym else timeit(lambda: nat.eps_slots_only(p, p, nat.CMP_LE, 2, 0, N, cap, si, sw, cnt))
-    tk = timeit(lambda: nat.knn_graph(p, p, 16, out=out))
-    print(f"AUTO {name}: eps2 slots ({'sym entry' if use_sym else 'rect entry'}) {te:.3f}  knn16 {tk:.3f}", flush=True)
+    rect = lambda: nat.eps_slots_only(p, p, nat.CMP_LE, 2, 0, N, cap, si, sw, cnt)
+    knn = lambda: nat.knn_graph(p, p, 16, out=out)
+    def forced(env, f):
+        os.environ.update(env); t = timeit(f)
+        for k_ in env: os.environ.pop(k_)
+        return t
+    te = timeit(sym) if use_sym else timeit(rect)
+    tk = timeit(knn)
+    # the forced combinations in the same process, on the same buffers (same box, same clocks)
+    fe = {"valu rect": forced({"PG_ENGINE": "valu"}, rect), "mfma rect": forced({"PG_ENGINE": "mfma"}, rect)}
+    if use_sym:
+        fe["valu sym"] = forced({"PG_ENGINE": "valu"}, sym); fe["mfma sym"] = forced({"PG_ENGINE": "mfma"}, sym)
+    fk = {"valu": forced({"PG_ENGINE": "valu"}, knn), "mfma R=1": forced({"PG_ENGINE": "mfma", "PG_MM_R": "1"}, knn),
+          "mfma R=2": forced({"PG_ENGINE": "mfma", "PG_MM_R": "2"}, knn)}
+    be, bk = min(fe, key=fe.get), min(fk, key=fk.get)
+    print(f"{name}\n  eps2 slots: AUTO {te:.3f}  best forced {be} {fe[be]:.3f}  auto/best {te / fe[be]:.3f}   ("
+          + ", ".join(f"{k_} {v:.3f}" for k_, v in fe.items()) + ")\n"
+          f"  knn16:      AUTO {tk:.3f}  best forced {bk} {fk[bk]:.3f}  auto/best {tk / fk[bk]:.3f}   ("
+          + ", ".join(f"{k_} {v:.3f}" for k_, v in fk.items()) + ")", flush=True)
