@@ -127,7 +127,9 @@ int pg_pack_bytes(const uint8_t *src, int64_t n, int width, int64_t ld, const in
  * pg_hamming_dense — all-pairs Hamming distance matrix.
  * Replaces `torch.sum(X != Y[:,None,:], axis=2)` (prograph/distance/hamming.py:34;
  * K2+K3 of SURVEY.md §2.2).  out[m*ldo + n] = #{j : Y[m,j] != X[n,j]}, (M,N) like the
- * reference.  out_elem_bytes in {1,4,8} (uint8 / int32 / int64 = the reference's dtype).
+ * reference.  out_elem_bytes in {1,2,4,8}: uint8 / fp16 / int32 / int64 (= the reference's dtype).
+ * fp16 holds the integer itself (exact up to 2048 positions): a block in that form is the operand of
+ * pg_f16_knn / pg_f16_eps_* below - graphs of sequences longer than one record of the fused engines.
  * accumulate != 0 adds to `out` instead of overwriting it: sequences longer than one record
  * (255 / 128 tokens) are handled as a sum over column segments packed separately.
  */

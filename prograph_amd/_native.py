@@ -284,7 +284,7 @@ def pack_bytes(raw, lut, bits=BITS_5, want_tokens=True, check=True):
     return planes, tokens
 
 
-_TORCH_OUT = {1: torch.uint8, 4: torch.int32, 8: torch.int64}
+_TORCH_OUT = {1: torch.uint8, 2: torch.float16, 4: torch.int32, 8: torch.int64}
 
 
 def hamming_dense(xp, yp, out_bytes=8, out=None):

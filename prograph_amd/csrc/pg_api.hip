@@ -582,8 +582,8 @@ int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad, const void
     return fail(PG_E_BADARG, "pg_hamming_dense: bad argument");
   if (int rc = check_bits(bits)) return rc;
   if (int rc = check_l(l, bits)) return rc;
-  if (out_elem_bytes != 1 && out_elem_bytes != 4 && out_elem_bytes != 8)
-    return fail(PG_E_BADARG, "pg_hamming_dense: out_elem_bytes must be 1, 4 or 8");
+  if (out_elem_bytes != 1 && out_elem_bytes != 2 && out_elem_bytes != 4 && out_elem_bytes != 8)
+    return fail(PG_E_BADARG, "pg_hamming_dense: out_elem_bytes must be 1, 2, 4 or 8");
   if (x_npad < n || x_npad % 256 || y_npad < m) return fail(PG_E_BADARG, "pg_hamming_dense: bad npad");
   if ((m + PG_RBD - 1) / PG_RBD > 65535) return fail(PG_E_BADARG, "pg_hamming_dense: m too large for one launch");
   DenseParams p;

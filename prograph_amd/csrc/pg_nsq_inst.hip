@@ -91,6 +91,8 @@ static int launch_dense(const DenseParams &p, hipStream_t s) {
     pg_dense_kernel<PG_G, B, long long><<<grid, dim3(PG_WG_THREADS), 0, s>>>(p);
   else if (p.outBytes == 4)
     pg_dense_kernel<PG_G, B, int><<<grid, dim3(PG_WG_THREADS), 0, s>>>(p);
+  else if (p.outBytes == 2)   // fp16 (integers up to 2048 are exact): the operand type of the fp16 selection kernels
+    pg_dense_kernel<PG_G, B, _Float16><<<grid, dim3(PG_WG_THREADS), 0, s>>>(p);
   else
     pg_dense_kernel<PG_G, B, unsigned char><<<grid, dim3(PG_WG_THREADS), 0, s>>>(p);
   return (int)hipGetLastError();

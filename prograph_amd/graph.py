@@ -14,7 +14,7 @@ from . import _native
 
 
 class CSRGraph:
-    """epsilon-neighbourhood graph: indptr int64 [n+1], indices int32 [nnz], weights uint8|float32 [nnz]."""
+    """epsilon-neighbourhood graph: indptr int64 [n+1], indices int32 [nnz], weights uint8|int16|float32 [nnz]."""
 
     def __init__(self, indptr, indices, weights, ncols, similarity=False, row0=0):
         self.indptr, self.indices, self.weights = indptr, indices, weights
@@ -54,6 +54,8 @@ class CSRGraph:
             return None
         if self.similarity:
             return (1 / (1 + self.weights.to(torch.int64))).to(torch.float32)
+        if self.weights.dtype not in (torch.uint8, torch.float32):
+            return self.weights.to(torch.float32)          # int16 distances of sequences beyond one record: exact
         return self.weights
 
     def row_stats(self, f=None, boolean_weights=False, want=("deg",)):

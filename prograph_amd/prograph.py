@@ -485,10 +485,15 @@ class Prograph:
                 native = False                      # not byte tokens / L > 128: generic torch path
         if native and k and planes.n > _native.MAX_N_KNN:
             native = False
-        if not native:
+        g = None
+        if not native and distance is hamming and comp in _CMP_CODE and (k is None or k <= _native.MAX_K):
+            g = self._build_graph_long(idxs, eps, k, similarity, representation, comp)
+        if not native and g is None:
             return self._build_graph_generic(idxs, batch_size, eps, k, similarity, representation, distance, comp)
 
-        if eps:
+        if g is not None:
+            pass                                    # sequences beyond one record of the fused engines: built above
+        elif eps:
             # similarity: comp(1/(1+eps), 1/(1+d)) & (s < 1) is the mirrored integer test on d
             # (:720-721, :734); both sides are the same correctly rounded float32 quotient when d == eps
             indptr, indices, wts = _native.eps_graph(planes, planes, _CMP_CODE[comp], eps, cap=cap)
@@ -510,6 +515,73 @@ class Prograph:
         if output == "csr":
             return g
         return tuples if tuples is not None else g.to_tuples()
+
+    _LONG_MAX_L = 2048                               # integers up to here are exact in fp16
+
+    def _build_graph_long(self, idxs, eps, k, similarity, representation, comp):
+        """
+        Graphs of byte-token sequences LONGER than one record of the fused engines (more than 255 positions,
+        128 for alphabets above 31 symbols; the reference has no limit: hamming.py:32-34 is a broadcast).
+        Per block of rows the distance matrix comes from the dense kernel - the sequence cut into column
+        segments of whole records, their distances accumulated in place (`pg_hamming_dense`, fp16 output:
+        integers up to 2048 are exact) - and the selection runs on the device as for fp16 embeddings: the
+        canonical (distance, column) ranks 1..k (`pg_f16_knn`; :756-763) or the thresholded CSR
+        (`pg_f16_eps_*`; :734-739).  Returns a KNNGraph / CSRGraph with int16 weights, or None when the
+        representation is not byte tokens or longer than 2048 positions (the generic batch loop then).
+        """
+        try:
+            mat = self.tokenized if representation == "Tokenized" else np.vstack(self(representation))
+            mat = np.asarray(mat)
+        except (ValueError, TypeError):
+            return None
+        if mat.ndim != 2 or not np.issubdtype(mat.dtype, np.integer) or mat.shape[0] == 0 or mat.shape[1] == 0:
+            return None
+        if mat.shape[1] > self._LONG_MAX_L or mat.min() < 0 or mat.max() > 255:
+            return None
+        if idxs is not None:
+            mat = mat[np.asarray(idxs)]
+        dev = _native.device()
+        T = torch.as_tensor(np.ascontiguousarray(mat.astype(np.uint8)), device=dev)
+        n, l = T.shape
+        bits = _native.BITS_5 if int(mat.max()) <= 31 else _native.BITS_8
+        w = (_native.MAX_L_5BIT if bits == _native.BITS_5 else _native.MAX_L) // 32 * 32   # whole 32-token groups
+        segs = [(a, min(l, a + w)) for a in range(0, l, w)]
+        xs = [_native.pack(T[:, a:b], bits=bits) for a, b in segs]
+        # comp(d, eps) on integer distances as an integer threshold (exact in fp16 whatever eps is);
+        # similarity graphs: comp(1/(1+eps), 1/(1+d)) & (s < 1) is the same test on d (:720-721, :734)
+        cmp = _CMP_CODE[comp]
+        if eps:
+            e = float(eps)
+            lo, hi = int(np.floor(e)), int(np.ceil(e))
+            thr = {_native.CMP_LE: lo, _native.CMP_LT: hi, _native.CMP_GE: hi, _native.CMP_GT: lo}.get(cmp, lo if lo == hi else -1)
+            thr = float(min(max(thr, -1), 4096))
+        rows_per_block = max(64, min(n, (1 << 27) // n))                  # <= 256 MB of fp16 distances at a time
+        kk = min(k, n - 1) if k else 0
+        parts = []
+        for r0 in range(0, n, rows_per_block):
+            r1 = min(n, r0 + rows_per_block)
+            block = None
+            for (a, b), xp in zip(segs, xs):
+                block = _native.hamming_dense(xp, _native.pack(T[r0:r1, a:b], bits=bits), out_bytes=2, out=block)
+            if k:
+                if kk:
+                    idx, wt = _native.f16_knn(block, kk, first=1, descending=False)
+                    parts.append((idx, wt.to(torch.int16)))
+            else:
+                indptr, indices, wts = _native.f16_eps(block, cmp, thr, similarity=False)
+                parts.append((indptr, indices, wts.to(torch.int16)))
+            del block
+        if k:
+            if not kk:
+                return KNNGraph(torch.zeros((n, 0), dtype=torch.int32, device=dev), torch.zeros((n, 0), dtype=torch.int16, device=dev),
+                                n, similarity=similarity)
+            return KNNGraph(torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts]), n, similarity=similarity)
+        base, ptrs = 0, [torch.zeros(1, dtype=torch.int64, device=dev)]
+        for indptr, _, _ in parts:
+            ptrs.append(indptr[1:] + base)
+            base += int(indptr[-1].item())
+        return CSRGraph(torch.cat(ptrs), torch.cat([p_[1] for p_ in parts]), torch.cat([p_[2] for p_ in parts]), n,
+                        similarity=similarity)
 
     def _build_graph_minkowski(self, idxs, eps, k, similarity, representation, comp):
         """

@@ -60,7 +60,7 @@ def _dense(xp, yp, out_bytes=8, out=None):
     if out is not None:
         out += d.to(out.dtype)
         return out
-    return d.to({1: torch.uint8, 4: torch.int32, 8: torch.int64}[out_bytes])
+    return d.to({1: torch.uint8, 2: torch.float16, 4: torch.int32, 8: torch.int64}[out_bytes])
 
 
 def _window(rp, cp, row0, nrows):
@@ -135,6 +135,21 @@ def _csr_row_stats(indptr, indices, weights, f=None, want=("deg",), row0=0, ncol
     return out
 
 
+def _f16_knn(block, k, first=1, descending=False):
+    s = torch.sort(block.to(torch.float32), dim=1, descending=bool(descending), stable=True)
+    return s[1][:, first:first + k].to(torch.int32), s[0][:, first:first + k].to(torch.float16)
+
+
+def _f16_eps(block, cmp, eps, similarity=False):
+    d = block.to(torch.float32)
+    e = float(np.float16(eps))
+    keep = (_OPS[cmp](e, d) & (d < 1)) if similarity else (_OPS[cmp](d, e) & (d > 0))
+    counts = keep.sum(dim=1)
+    indptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)])
+    rows, cols = torch.where(keep)
+    return indptr, cols.to(torch.int32), block[rows, cols]
+
+
 def install(monkeypatch):
     monkeypatch.setattr(_native, "device", lambda: torch.device("cpu"))
     monkeypatch.setattr(_native, "pack", _pack)
@@ -144,3 +159,5 @@ def install(monkeypatch):
     monkeypatch.setattr(_native, "index_flags", _index_flags)
     monkeypatch.setattr(_native, "compact_flags", _compact_flags)
     monkeypatch.setattr(_native, "csr_row_stats", _csr_row_stats)
+    monkeypatch.setattr(_native, "f16_knn", _f16_knn)
+    monkeypatch.setattr(_native, "f16_eps", _f16_eps)

@@ -150,6 +150,14 @@ def test_dense_vs_oracle_all_q(nat):
         for bits in (BITS if L <= 128 else [5]):
             out = nat.hamming_dense(_planes(nat, X, bits), _planes(nat, Y, bits))
             assert np.array_equal(out.cpu().numpy(), ref), (L, bits)
+            # every output type; the fp16 form (the selection kernels' operand) with in-place accumulation as well
+            for nbytes in (1, 2, 4):
+                o = nat.hamming_dense(_planes(nat, X, bits), _planes(nat, Y, bits), out_bytes=nbytes)
+                assert np.array_equal(o.cpu().numpy().astype(np.int64), ref), (L, bits, nbytes)
+            acc = nat.hamming_dense(_planes(nat, X, bits), _planes(nat, Y, bits), out_bytes=2)
+            for _ in range(7):                                 # 8 x 255 = 2040: still exact in fp16
+                acc = nat.hamming_dense(_planes(nat, X, bits), _planes(nat, Y, bits), out=acc)
+            assert np.array_equal(acc.cpu().numpy().astype(np.int64), 8 * ref), (L, bits)
 
 
 def test_engine_vs_oracle_all_q(nat, engine, monkeypatch):

@@ -484,15 +484,40 @@ def test_sequences_beyond_the_fused_limits(backend, tmp_path, capsys):
     d7 = O.hamming(t64, t64[7:8]).numpy()[0]
     assert np.array_equal(pg.calc_neighbours(seq7, eps=int(np.sort(d7)[3]), comp=operator.le), np.nonzero(d7 <= np.sort(d7)[3])[0])
     assert list(pg.neighbourhood(seq7, 4).index) == list(np.nonzero(d7 <= 4)[0])
-    # graphs through the batch loop over the native dense operator
+    # graphs: dense kernel over column segments (fp16-coded integers) + the device selection kernels - NOT the
+    # torch batch loop: every row against the oracle, every comparator, similarity, stored device graphs
+    def no_generic(*a, **kw):
+        raise AssertionError("long byte-token sequences must not take the generic batch loop")
+    pg._build_graph_generic = no_generic
+    D = O.hamming(t64, t64).numpy()
     g = pg.build_graph(k=5)
     e = pg.build_graph(eps=4)
-    for r in (0, 5, 45, 399):
-        d = O.hamming(t64, t64[r:r + 1]).numpy()[0]
-        order = np.argsort(d, kind="stable")[1:6]
-        assert np.array_equal(g[r][0], order) and np.array_equal(g[r][1], d[order])
-        cols = np.nonzero((d <= 4) & (d > 0))[0]
-        assert np.array_equal(e[r][0], cols) and np.array_equal(e[r][1], d[cols])
+    assert len(g) == N and len(e) == N
+    for r in range(N):
+        order = np.argsort(D[r], kind="stable")[1:6]
+        assert np.array_equal(g[r][0], order) and np.array_equal(g[r][1], D[r][order])
+        cols = np.nonzero((D[r] <= 4) & (D[r] > 0))[0]
+        assert np.array_equal(e[r][0], cols) and np.array_equal(e[r][1], D[r][cols])
+        assert g[r][1].dtype == np.int64 and (len(cols) == 0 or e[r][1].dtype == np.int64)
+    far = int(np.sort(D[3])[N // 2])                           # a threshold among unrelated sequences (d > 255)
+    assert far > 255
+    for comp, eps in ((operator.lt, far), (operator.ge, far + 0.5), (operator.gt, far), (operator.eq, far), (operator.eq, 4.5),
+                      (operator.le, 4.999)):
+        got = pg.build_graph(eps=eps, comp=comp)
+        for r in (0, 3, 5, 45, 399):
+            cols = np.nonzero(comp(D[r], eps) & (D[r] > 0))[0]
+            assert np.array_equal(got[r][0], cols) and np.array_equal(got[r][1], D[r][cols]), (comp, eps, r)
+    s = pg.build_graph(k=3, similarity=True)
+    for r in (0, 5, 45):
+        order = np.argsort(D[r], kind="stable")[1:4]
+        assert np.array_equal(s[r][0], order) and np.allclose(s[r][1], 1 / (1 + D[r][order]))
+    sub = pg.build_graph(k=2, idxs=[0, 5, 45, 7, 300])
+    Ds = D[np.ix_([0, 5, 45, 7, 300], [0, 5, 45, 7, 300])]
+    for r in range(5):
+        assert np.array_equal(sub[r][0], np.argsort(Ds[r], kind="stable")[1:3])
+    pg.build_graph(eps=4, store="Near")                        # analytics from the device CSR (int16 weights)
+    deg = pg.degree(graph="Near")
+    assert np.array_equal(deg, np.array([D[r][(D[r] <= 4) & (D[r] > 0)].sum() for r in range(N)], dtype=np.float32))
 
 
 @pytest.fixture

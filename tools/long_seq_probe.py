@@ -1,5 +1,5 @@
-"""Graph construction for sequences beyond the fused engine's limits (L > 255): the batch loop over
-the native dense operator."""
+"""Graph construction for sequences beyond the fused engines' record (L > 255): dense kernel over column segments +
+device selection (`Prograph._build_graph_long`), beside the generic batch loop (torch sort / where over the same operator)."""
 import os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pandas as pd, torch
@@ -22,3 +22,7 @@ for r in rows:
     cols = np.where((d <= 3) & (d > 0))[0]
     assert np.array_equal(e[r][0], cols) and np.array_equal(e[r][1], d[cols]), r
 print("sampled rows match the oracle")
+from prograph_amd.distance import hamming
+t = time.time(); g2 = pg._build_graph_generic(None, 8, None, 8, False, "Tokenized", hamming, None); torch.cuda.synchronize()
+print(f"generic batch loop, k=8: {time.time()-t:.2f} s;  same graph: {all(np.array_equal(a[0], b[0]) for a, b in zip(g, g2))}")
+t = time.time(); gc = pg.build_graph(k=8, output="csr"); torch.cuda.synchronize(); print(f"build_graph(k=8, output='csr') (no tuples): {time.time()-t:.3f} s")
