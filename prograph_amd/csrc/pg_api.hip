@@ -638,6 +638,18 @@ extern "C" int pg_debug_stats(unsigned long long *out12, int reset) {   // debug
 #endif
 static const nsq_fn kMm[8] = {pg_launch_mm_g1, pg_launch_mm_g2, pg_launch_mm_g3, pg_launch_mm_g4,
                               pg_launch_mm_g5, pg_launch_mm_g6, pg_launch_mm_g7, pg_launch_mm_g8};
+// resident workgroups per CU of an MFMA-engine instance (launcher mode codes 0..4), asked once from the runtime
+static int mm_occupancy(int groups, int mode, int bits) {
+  static std::atomic<int> cache[8][5][2];                  // (a property of the code object: the same on every gfx950)
+  std::atomic<int> &c = cache[groups - 1][mode][bits == 8];
+  int v = c.load(std::memory_order_relaxed);
+  if (v == 0) {
+    const int n = kMm[groups - 1](mode, bits, NsqParams(), -1, nullptr);
+    v = n < 1 ? 4 : (n > 4 ? 4 : n);
+    c.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 // One pass per wave.  A pass takes up to 32 rows (the M of the MFMA tile) and the CU holds 16 waves (four
 // workgroups: LDS and VGPR bound), so the grid runs in rounds of `slots` passes.  When 32-row passes would not
 // even fill one round, the rows are spread over ~97 % of the slots in smaller passes, down to 16 rows (N=50k L=32
@@ -646,14 +658,34 @@ static const nsq_fn kMm[8] = {pg_launch_mm_g1, pg_launch_mm_g2, pg_launch_mm_g3,
 // slower (dense 200k: 12.5 -> 14.1 ms, cfg3 3.81 -> 3.90) - a round of 2154 full passes on half-empty SIMDs runs
 // faster per pass than 3830 passes of 18 rows on full ones - and therefore off.
 // PG_ROWS_PER_WAVE = uniform passes of that many rows (tuning sweeps).
-static void plan_mm(int64_t nrows, NsqParams *p, int *grid, int rb = PG_MM_RB) {   // rb: rows per pass of the instance (32 or 64)
+// occ: resident workgroups per CU of the instance (= waves per SIMD), mm_occupancy().
+// Single round (every pass gets a wave slot at once): what a launch takes follows the waves on its busiest SIMD, not the
+// rows per wave - every wave streams all column fragments through the matrix pipe whatever its row count (measured at
+// 200 000 columns, tools/dbg/balance*.py: one wave per SIMD 0.70 ms, two 0.79, three 0.94, four 1.10-1.14 with 32-row
+// passes; 1.26 / 1.52 / 1.87 for two / three / four waves of 64-row passes, the same for 48..64 rows).  So: the fewest
+// waves per SIMD that hold the rows, the rows spread evenly over exactly that many waves on every SIMD.  (Round 2 spread
+// the rows over ~97 % of ALL slots: 65 536 rows took 1.11 ms as 4096 passes of 16 rows, 0.79 as 2048 of 32.)
+static void plan_mm(int64_t nrows, NsqParams *p, int *grid, int rb = PG_MM_RB, int occ = 4, bool knn = false) {   // rb: rows per pass of the instance (32 or 64)
   long long rpw = rb, tailFrom = (nrows + rb - 1) / rb, tailRows = rb;
-  const long long slots = (long long)(cu_count() > 0 ? cu_count() : 256) * 16;
+  const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4;
+  const long long slots = simds * (occ < 1 ? 1 : occ);
   const char *e = getenv("PG_ROWS_PER_WAVE");
   const char *t = getenv("PG_MM_TAIL");
+  // eps launches keep round 2's spreading rule: their passes are not equal work (symmetric: a pass sweeps the columns
+  // above its rows only; matches cost per row) - tools/dbg/plan_ab.py: N = 50k eps <= 2 symmetric 0.58 ms against 0.79
+  const bool oldPlan = !knn || (getenv("PG_MM_PLAN") && atoi(getenv("PG_MM_PLAN")) == 2);   // (A/B: PG_MM_PLAN=2)
   if (e && atoi(e) > 0) {
     rpw = atoi(e) < rb ? atoi(e) : rb;                      // (a wave sweeps one pass of at most rb rows at a time)
     tailFrom = (nrows + rpw - 1) / rpw; tailRows = rpw;
+  } else if (!oldPlan) {
+    if (tailFrom <= slots) {
+      const long long w = (tailFrom + simds - 1) / simds;               // waves per SIMD
+      long long r = (nrows + w * simds - 1) / (w * simds);
+      r = (r + 1) / 2 * 2;
+      if (r < 4) r = 4;
+      if (r > rb) r = rb;
+      rpw = r; tailFrom = (nrows + r - 1) / r; tailRows = r;
+    }
   } else {
     const long long full = nrows / (slots * rb) * slots;                // passes of the full rounds
     const long long rest = nrows - full * rb;
@@ -886,16 +918,22 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
                            !(getenv("PG_MM_SHORT") && atoi(getenv("PG_MM_SHORT")) == 0);
     // ... with 64 rows per pass (every column fragment feeds two MFMAs: half the vector-memory traffic per pair)
     // where passes of 64 still fill most of the chip's wave slots; PG_MM_R=1 / 2 forces either
-    const long long slots = (long long)(cu_count() > 0 ? cu_count() : 256) * 16;
-    bool two = shortList && nrows >= 64 * slots * 6 / 10;
+    // once 32-row passes no longer get a wave slot each (measured, tools/dbg/balance*.py, rows x 200 000 columns: 131 072
+    // rows 1.14 ms against 1.26; 147 456: 1.55 / 1.47; 196 608: 1.84 / 1.57); PG_MM_R=1 / 2 forces either
+    const int ng = pg_ngroups(l);
+    const int occ1 = mm_occupancy(ng, shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN, bits);
+    const long long slots1 = (long long)(cu_count() > 0 ? cu_count() : 256) * 4 * occ1;
+    // (byte alphabets: the 64-row instance holds two waves per SIMD, the 32-row one three - 200k rows 2.47 ms against 2.30)
+    const int occ2 = shortList ? mm_occupancy(ng, PG_MODE_KNN_SHORT2, bits) : 0;
+    bool two = shortList && (nrows + PG_MM_RB - 1) / PG_MM_RB > slots1 && occ2 >= 3;
     if (const char *e = getenv("PG_MM_R")) two = shortList && atoi(e) == 2;
-    plan_mm(nrows, &p, &grid, two ? 2 * PG_MM_RB : PG_MM_RB);
+    plan_mm(nrows, &p, &grid, two ? 2 * PG_MM_RB : PG_MM_RB, two ? occ2 : occ1, true);
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
     if (two && p.gate && !getenv("PG_MM_R")) {
       // the probe may say "one cluster" (gate 2): the same engine with 32-row passes, launched as a third alternative
       NsqParams q = p;
       int qgrid = 0;
-      plan_mm(nrows, &q, &qgrid, PG_MM_RB);
+      plan_mm(nrows, &q, &qgrid, PG_MM_RB, occ1, true);
       q.mmPassCounter = p.mmPassCounter + 8;
       q.gateWant = 2u;
       if (int rc = launched(kMm[pg_ngroups(l) - 1](PG_MODE_KNN_SHORT, bits, q, qgrid, (hipStream_t)stream), "pg_mm_kernel(knn, 32-row passes, gated)")) return rc;

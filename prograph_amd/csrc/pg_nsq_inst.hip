@@ -61,9 +61,15 @@ int PG_CAT(pg_launch_nsq_g, PG_G)(int mode, int bits, const NsqParams &p, int gr
   return bits == 5 ? launch_nsq<5, PG_MODE_KNN>(p, grid, s) : launch_nsq<8, PG_MODE_KNN>(p, grid, s);
 }
 
+// grid < 0: no launch - the instance's resident workgroups per CU (0: unknown), for the planner
 template <int B, int MODE, int KL = 64, int R = 1>
 static int launch_mm(const NsqParams &p, int grid, hipStream_t s) {
   if constexpr (Cols<B>::kBuilt) {
+    if (grid < 0) {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pg_mm_kernel<HammingMetric<PG_G, B>, MODE, KL, R>, PG_WG_THREADS, 0) != hipSuccess) n = 0;
+      return n;
+    }
     pg_mm_kernel<HammingMetric<PG_G, B>, MODE, KL, R><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
     return (int)hipGetLastError();
   } else {

@@ -10,7 +10,7 @@ def t(f, iters=5):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return float(np.median(ts))
-for N, L in ((8000, 64), (16000, 64), (24000, 32), (32000, 64), (50000, 32), (50000, 64), (65000, 64), (65000, 128), (100000, 64)):
+for N, L in ((4000, 64), (8000, 64), (12000, 64), (16000, 64), (16000, 32), (24000, 32), (32000, 64), (50000, 32), (50000, 64), (65000, 64), (65000, 128), (100000, 64)):
     tok = synth.clustered_tokens(N, L)
     p = nat.pack(torch.from_numpy(tok), bits=5)
     out = (torch.empty((N, 16), dtype=torch.int32, device=p.buf.device), torch.empty((N, 16), dtype=torch.uint8, device=p.buf.device))
