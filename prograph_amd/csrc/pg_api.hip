@@ -80,7 +80,14 @@ int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunk
 // launch-private device state of an all-pairs call: today the pass counter of the persistent waves (one word in a
 // 64-byte line of its own); sized by the row count so that later per-row state needs no ABI change
 // [0, 64) the pass counter, [64, 128) the probe's decision words (gates), [128, 128 + 8 * PG_PROBE_ROWS * PG_PROBE_WAVES) its counts
-int64_t pg_workspace_bytes(int64_t nrows) { (void)nrows; return 128 + 8 * 64 * 128; }
+// from PG_WS_PARTIAL on: the lists of the column pieces (knn_launch: the rows one full round of waves cannot hold) -
+// at most PG_SPLIT_MAX_ROWS rows x 8 pieces (or half of them x 16) x PG_MM_KL keys
+#define PG_WS_PARTIAL (128 + 8 * 64 * 128)
+#define PG_SPLIT_MAX_ROWS 8192
+#define PG_SPLIT_MIN_ROWS 131072    // (launches below never split)
+int64_t pg_workspace_bytes(int64_t nrows) {
+  return PG_WS_PARTIAL + (nrows > PG_SPLIT_MIN_ROWS ? (int64_t)PG_SPLIT_MAX_ROWS * 8 * PG_MM_KL * 4 + 4 * (PG_SPLIT_MAX_ROWS / (2 * PG_MM_RB)) : 0);
+}
 
 }  // extern "C"
 
@@ -409,6 +416,39 @@ __global__ __launch_bounds__(1024) void pg_decide_kernel(const u32 *counts, int 
     gate[1] = force >= 0 ? (u32)((force >> 1) & 1) : (eps * 25ull > (unsigned long long)nsample * (unsigned long long)ncols ? 1u : 0u);
   }
 }
+// kNN of rows swept in column pieces (NsqParams::mmPieces): a row's `pieces` lists of k + 1 keys each -> its k + 1
+// smallest keys, ranks 1..k written out (the reference drops sorted rank 0, prograph/prograph.py:761-763).  One wave per
+// row; a key's rank = the keys below it (keys are distance << 24 | column: unique, except 0xFFFFFFFF = no entry).
+// A piece's list is exact below the optimistic cap only (NsqParams::mmPieces): a row whose merged (k+1)-th distance is
+// not below `cap` flags its block of `blockRows` rows for the repair launch.
+__global__ __launch_bounds__(PG_WG_THREADS) void pg_knn_merge_kernel(const u32 *partial, long long nrows, int pieces, int k, int *idx,
+                                                                     unsigned char *dist, u32 cap, int blockRows, u32 *blockFlags,
+                                                                     const u32 *gate, u32 gateWant) {
+  __shared__ u32 keys[PG_WG_WAVES][16 * PG_MM_KL];
+  if (gate && __builtin_nontemporal_load(gate) != gateWant) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * PG_WG_WAVES + wv;
+  if (row >= nrows) return;                                // (whole wave; no workgroup barrier below)
+  const int n = pieces * (k + 1);
+  for (int e = lane; e < n; e += 64) keys[wv][e] = partial[row * n + e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int e = lane; e < n; e += 64) {
+    const u32 key = keys[wv][e];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const u32 kj = keys[wv][j];
+      rank += (kj < key || (kj == key && j < e)) ? 1 : 0;
+    }
+    if (rank >= 1 && rank <= k) {
+      idx[row * k + rank - 1] = key == 0xFFFFFFFFu ? -1 : (int)(key & 0x00FFFFFFu);
+      dist[row * k + rank - 1] = (unsigned char)(key >> 24);
+    }
+    if (rank == k && (key >> 24) >= cap) blockFlags[row / blockRows] = 1u;   // (0xFFFFFFFF, no entry, reads 255)
+  }
+}
+
 typedef int (*probe_fn)(int, const ProbeParams &, hipStream_t);
 static const probe_fn kProbe[8] = {pg_launch_probe_g1, pg_launch_probe_g2, pg_launch_probe_g3, pg_launch_probe_g4,
                                    pg_launch_probe_g5, pg_launch_probe_g6, pg_launch_probe_g7, pg_launch_probe_g8};
@@ -927,8 +967,52 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     const int occ2 = shortList ? mm_occupancy(ng, PG_MODE_KNN_SHORT2, bits) : 0;
     bool two = shortList && (nrows + PG_MM_RB - 1) / PG_MM_RB > slots1 && occ2 >= 3;
     if (const char *e = getenv("PG_MM_R")) two = shortList && atoi(e) == 2;
-    plan_mm(nrows, &p, &grid, two ? 2 * PG_MM_RB : PG_MM_RB, two ? occ2 : occ1, true);
+    // One wave more on every SIMD for a few rows more costs the launch as much as a full round of them (plan_mm).
+    // Rows that one round of waves fewer holds go first; the few beyond - at most PG_SPLIT_MAX_ROWS - follow in a launch
+    // of their own where every pass sweeps one PIECE of the columns (as many pieces as give every SIMD about one
+    // wave: short passes, a sixteenth or an eighth of a sweep each), and pg_knn_merge_kernel makes the rows' lists of the pieces'.
+    // cfg3 (200 000 rows = 3 x 65 536 + 3 392): three waves per SIMD + 53 row blocks x 16 pieces.  PG_MM_SPLIT=0: off
+    long long mainRows = nrows;
+    if (two && workspace && p.knnGuess > 0 && ncols >= 65536 && nrows > PG_SPLIT_MIN_ROWS && !getenv("PG_ROWS_PER_WAVE") &&
+        !(getenv("PG_MM_SPLIT") && atoi(getenv("PG_MM_SPLIT")) == 0)) {
+      const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4, rb2 = 2 * PG_MM_RB;
+      const long long w = ((nrows + rb2 - 1) / rb2 + simds - 1) / simds;
+      const long long held = (w - 1) * simds * rb2;
+      if (w >= 3 && w <= occ2 && nrows - held <= PG_SPLIT_MAX_ROWS) mainRows = held;
+    }
+    plan_mm(mainRows, &p, &grid, two ? 2 * PG_MM_RB : PG_MM_RB, two ? occ2 : occ1, true);
+    p.nrows = mainRows;
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
+    if (mainRows < nrows) {
+      NsqParams q = p;
+      const long long rem = nrows - mainRows, nb = (rem + 2 * PG_MM_RB - 1) / (2 * PG_MM_RB);
+      const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4;
+      int pieces = (int)(simds / nb);
+      pieces = pieces > 16 ? 16 : (pieces < 2 ? 2 : pieces);
+      if (const char *e = getenv("PG_MM_PIECES")) { if (atoi(e) >= 2 && atoi(e) <= 16) pieces = atoi(e); }   // (experiments)
+      if (rem > PG_SPLIT_MAX_ROWS / 2 && pieces > 8) pieces = 8;        // (the workspace holds 8 pieces of 8192 rows or 16 of 4096)
+      q.row0 = p.row0 + mainRows; q.nrows = rem;
+      q.rowsPerWave = 2 * PG_MM_RB; q.rowsPerPass = 2 * PG_MM_RB; q.mmTailFrom = nb; q.mmTailRows = 2 * PG_MM_RB;
+      q.mmPieces = pieces; q.mmPartial = (u32 *)((char *)workspace + PG_WS_PARTIAL);
+      q.mmPasses = nb * pieces;
+      q.mmGridWaves = (q.mmPasses + PG_WG_WAVES - 1) / PG_WG_WAVES * PG_WG_WAVES;   // (one wave per pass: fewer than the chip's slots)
+      q.mmPassCounter = p.mmPassCounter + 4;
+      if (int rc = launched(kMm[ng - 1](PG_MODE_KNN_SHORT2, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn)")) return rc;
+      if (int rc = launched(kMm[ng - 1](PG_MODE_KNN_SHORT2, bits, q, (int)(q.mmGridWaves / PG_WG_WAVES), (hipStream_t)stream), "pg_mm_kernel(knn, column pieces)")) return rc;
+      u32 *flags = (u32 *)((char *)workspace + PG_WS_PARTIAL + (size_t)PG_SPLIT_MAX_ROWS * 8 * PG_MM_KL * 4);   // one word per row block
+      if (hipError_t e = hipMemsetAsync(flags, 0, (size_t)nb * 4, (hipStream_t)stream); e != hipSuccess) return hipfail(e, "workspace: hipMemsetAsync");
+      pg_knn_merge_kernel<<<dim3((unsigned)((rem + PG_WG_WAVES - 1) / PG_WG_WAVES)), dim3(PG_WG_THREADS), 0, (hipStream_t)stream>>>(
+          q.mmPartial, rem, pieces, k, idx_out + mainRows * k, dist_out + mainRows * k, p.knnGuess, 2 * PG_MM_RB, flags, p.gate, p.gateWant);
+      if (int rc = launched((int)hipGetLastError(), "pg_knn_merge_kernel")) return rc;
+      // the repair launch: the same rows in plain 64-row passes, the blocks the merge did not flag skipped
+      NsqParams f = q;
+      f.mmPieces = 0; f.mmPartial = nullptr; f.mmBlockFlags = flags;
+      f.mmPasses = nb; f.mmGridWaves = (nb + PG_WG_WAVES - 1) / PG_WG_WAVES * PG_WG_WAVES;
+      f.mmPassCounter = p.mmPassCounter + 12;
+      f.knnIdx = idx_out + mainRows * k; f.knnDist = dist_out + mainRows * k;
+      if (int rc = launched(kMm[ng - 1](PG_MODE_KNN_SHORT2, bits, f, (int)(f.mmGridWaves / PG_WG_WAVES), (hipStream_t)stream), "pg_mm_kernel(knn, repair)")) return rc;
+      p.nrows = nrows;                                      // (the gated 32-row alternative below covers all rows)
+    }
     if (two && p.gate && !getenv("PG_MM_R")) {
       // the probe may say "one cluster" (gate 2): the same engine with 32-row passes, launched as a third alternative
       NsqParams q = p;
@@ -938,6 +1022,7 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
       q.gateWant = 2u;
       if (int rc = launched(kMm[pg_ngroups(l) - 1](PG_MODE_KNN_SHORT, bits, q, qgrid, (hipStream_t)stream), "pg_mm_kernel(knn, 32-row passes, gated)")) return rc;
     }
+    if (mainRows < nrows) return 0;                         // (the main launch and the pieces are out already)
     return launched(kMm[pg_ngroups(l) - 1](two ? PG_MODE_KNN_SHORT2 : (shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN), bits, p, grid,
                                            (hipStream_t)stream), "pg_mm_kernel(knn)");
   }

@@ -174,9 +174,26 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   // grid; persistent waves spread that round over all SIMDs, where its waves run faster (fewer per SIMD).
   for (long long pass = gw; pass < p.mmPasses;) {
     // the rows of the pass: rowsPerWave each, mmTailRows from pass mmTailFrom on
-    const bool tailPass = pass >= p.mmTailFrom;
+    if constexpr (kPar) {
+      // (the repair launch behind a launch in column pieces: only the row blocks the merge flagged)
+      if (p.mmBlockFlags && __builtin_nontemporal_load(&p.mmBlockFlags[pass]) == 0u) {
+        u32 nx = 0;
+        if (lane == 0) nx = atomicAdd(p.mmPassCounter, 1u);
+        pass = p.mmGridWaves + (long long)(u32)__builtin_amdgcn_readfirstlane((int)nx);
+        continue;
+      }
+    }
+    // (column pieces, kPar instances: pass = row block * pieces + piece; uniform passes of rowsPerWave rows)
+    const int npieces = kPar && p.mmPieces > 1 ? p.mmPieces : 1;
+    const long long rpass = npieces > 1 ? pass / npieces : pass;
+    const int piece = npieces > 1 ? (int)(pass - rpass * npieces) : 0;
+    const bool tailPass = rpass >= p.mmTailFrom;
     const long long prows = tailPass ? p.mmTailRows : p.rowsPerWave;
-    const long long pr0 = tailPass ? p.mmTailFrom * p.rowsPerWave + (pass - p.mmTailFrom) * p.mmTailRows : pass * p.rowsPerWave;
+    const long long pr0 = tailPass ? p.mmTailFrom * p.rowsPerWave + (rpass - p.mmTailFrom) * p.mmTailRows : rpass * p.rowsPerWave;
+    // the super-tiles of this pass: all of them, or the piece's share (whole pairs of super-tiles: the folded form's tiles)
+    const int npair = (nst + 1) >> 1;
+    const int sb = npieces > 1 ? 2 * (int)((long long)npair * piece / npieces) : 0;
+    const int se = npieces > 1 ? (2 * (int)((long long)npair * (piece + 1) / npieces) < nst ? 2 * (int)((long long)npair * (piece + 1) / npieces) : nst) : nst;
     const long long left = (pr0 + prows < p.nrows ? pr0 + prows : p.nrows) - pr0;
     PG_ST(10, 1);
     PG_T0(tp0);
@@ -917,7 +934,8 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // queue drained first - at the first position it reaches from there (the one site shared with the end-of-sweep
     // drain: one copy of flush).  No checkpoints without a cap and in phase 1.
     constexpr int kNoCk = 0x7FFFFFFF;
-    int nextCk = (MODE == PG_MODE_KNN && G0) ? ((nst + 31) >> 5) : kNoCk;
+    // (a column piece keeps the cap to its end: what the cap hides from it, the merge detects - NsqParams::mmPieces)
+    int nextCk = (MODE == PG_MODE_KNN && G0 && npieces == 1) ? ((nst + 31) >> 5) : kNoCk;
     auto checkpoint = [&](int snext) {                      // the sweep has reached super-tile snext >= nextCk; queue empty
       if constexpr (MODE == PG_MODE_KNN) {
         const int sw2 = (nst + 7) >> 3;
@@ -1002,9 +1020,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     };
 
     PG_T1(21, tp0);
-    int send = nst;
+    int send = se;
     int drun = 0;                                           // super-tiles per dense run (0: the first of a series)
-    const int sbeg = kSym ? (int)(pr0 / PG_MM_ST) : 0;     // EPS_SYM: from the super-tile that holds the pass's first row
+    const int sbeg = kSym ? (int)(pr0 / PG_MM_ST) : sb;    // EPS_SYM: from the super-tile that holds the pass's first row
     for (;;) {
       int S = sbeg;
       int dEnd = canFilter ? 0 : send;                      // a dense run is in progress up to here (no filter: throughout)
@@ -1062,8 +1080,16 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     } else {
       const auto &kr = K();
       if constexpr (kPar) {
-        // the pass's nr x k results are one contiguous stretch of the output: coalesced stores
         const int kk = kr.k;
+        if (npieces > 1) {
+          // a column piece: the list as it stands (k + 1 keys, rank 0 included) for the merge
+          const int k1 = kk + 1;
+          for (int e = lane; e < nr * k1; e += 64) {
+            const int rr = e / k1, j = e - rr * k1;
+            kr.mmPartial[((pr0 + rr) * (long long)npieces + piece) * k1 + j] = lstbuf[wv][rr][KL - k1 + j];
+          }
+        } else
+        // the pass's nr x k results are one contiguous stretch of the output: coalesced stores
         for (int e = lane; e < nr * kk; e += 64) {
           const int rr = e / kk, j = e - rr * kk;
           const u32 key = lstbuf[wv][rr][KL - kk + j];

@@ -374,6 +374,39 @@ def test_full_matrix_parity_at_the_headline_sizes(nat, cfg):
 
 
 @one_engine
+@pytest.mark.parametrize("case", ["cfg3", "clusters of 64", "139000 rows", "clusters of 12, forced"])
+def test_rows_beyond_a_full_round_in_column_pieces(nat, case, monkeypatch):
+    """A launch whose rows need one wave more per SIMD only for a few rows (200 000 = 3 x 65 536 + 3 392) sweeps those
+    rows in column pieces, merges the pieces' lists and repairs the row blocks the optimistic cap may have cut short
+    (pg_api.hip knn_launch).  Against the oracle on ALL of the split-off rows, and against the unsplit launch on every
+    row; cluster sizes where no piece holds k + 1 mates (64 members in 16 pieces) and where not even the whole matrix
+    does (12 members: every block goes to the repair launch); 2, 7 and 16 pieces."""
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    k = 16
+    N, members = {"cfg3": (200_000, 256), "clusters of 64": (200_000, 64), "139000 rows": (139_000, 256),
+                  "clusters of 12, forced": (200_000, 12)}[case]
+    held = (N - 1) // 65536 * 65536
+    tok = synth.clustered_tokens(N, 64, members=members)
+    p = nat.pack(torch.from_numpy(tok), bits=5)
+    monkeypatch.setenv("PG_ENGINE", "mfma")                   # (no probe: 12-member clusters would go to the VALU engine)
+    monkeypatch.setenv("PG_MM_SPLIT", "0")
+    ref_i, ref_d = nat.knn_graph(p, p, k)
+    monkeypatch.delenv("PG_MM_SPLIT")
+    ridx, rd = C.knn(tok, k, row0=held, nrows=N - held, fast=True)
+    for pieces in (None, "2", "7", "16") if case == "cfg3" else (None,):
+        if pieces:
+            monkeypatch.setenv("PG_MM_PIECES", pieces)
+        kidx, kd = nat.knn_graph(p, p, k)
+        torch.cuda.synchronize()
+        assert np.array_equal(kidx[held:].cpu().numpy(), ridx) and np.array_equal(kd[held:].cpu().numpy(), rd), (case, pieces)
+        assert bool((kidx == ref_i).all()) and bool((kd == ref_d).all()), (case, pieces)
+    # a window of rows of a larger matrix (row0 > 0) that ends a few rows past a full round
+    kidx, kd = nat.knn_graph(p, p, k, row0=1000, nrows=131_072 + 700)
+    assert bool((kidx == ref_i[1000:1000 + 131_772]).all()) and bool((kd == ref_d[1000:1000 + 131_772]).all())
+
+
+@one_engine
 def test_full_windows_on_dense_data_and_on_the_sharded_slice(nat):
     """Whole 4 096-row windows against the oracle where a full matrix is out of reach on the host: (i) cfg3's shape on
     DENSE data (one cluster: the folded / exact forms of the engine), (ii) rank 3's block of BASELINE.json configs[3]
