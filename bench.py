@@ -372,28 +372,28 @@ def roofline(rec, wl, pmc, sha):
         alg_bytes = float(N) * N * (2 * L + 2)
         return {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instructions/s", "frac": achieved / VALU_PEAK,
                 "traffic": None, "kernel": "pg_minkowski_dense (+ pg_pack_f16, pg_f16_knn)", "kernel_ms": rec["kern_ms"],
-                "valu_wave_instr_per_launch": valu,
+                "valu_wave_instr_per_step": valu,
                 "hbm_equivalent": {"achieved_GBs": alg_bytes / (rec["kern_ms"] * 1e-3) / 1e9, "algorithmic_bytes": alg_bytes,
                                    "note": "2*D bytes of fp16 operand per ordered pair + the fp16 distance"},
                 "note": "algorithmic instruction count 1.5 * D * N^2 / 64 (not a counter); kernel_ms spans all launches of a step"}
     out_bytes = 5 * k * rows_local if wl["mode"] in ("knn", "lev") else 8 * (rows_local + 1) + 5 * rec["result"].get("nnz", 0)
-    alg_bytes = float(rows_local) * N * L + rows_local * L + out_bytes      # SURVEY.md §8-d, per launch
+    alg_bytes = float(rows_local) * N * L + rows_local * L + out_bytes      # SURVEY.md §8-d, per step
     hbm_eq = alg_bytes / (rec["kern_ms"] * 1e-3) / 1e9
     p = pmc.get(rec["name"]) or {}
     fresh = bool(p) and p.get("kernel_src_sha") == sha
-    valu = p.get("valu_wave_instr_per_launch") if fresh else None
+    valu = p.get("valu_wave_instr_per_step") if fresh else None
     if wl["mode"] == "lev" and fresh:
         # kernel_ms spans ALL launches of a Levenshtein step, so does the instruction count (profile + bag filter +
         # pack + exact distances / selection, summed per step by tools/summarize_prof.py)
         valu = p.get("valu_wave_instr_per_step_all_kernels")
-    mfma = p.get("mfma_instr_per_launch") if fresh else None
+    mfma = p.get("mfma_instr_per_step") if fresh else None
     achieved = valu / (rec["kern_ms"] * 1e-3) if valu else None
     r = {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instructions/s",
          "frac": achieved / VALU_PEAK if achieved else None,
-         "traffic": p.get("hbm_bytes_per_launch") if fresh else None,
+         "traffic": p.get("hbm_bytes_per_step") if fresh else None,
          "kernel": p.get("kernel_name") if fresh else ("pg_mm_kernel" if rec["engine"] == "mfma" else "pg_nsq_kernel"),
          "kernel_ms": rec["kern_ms"],
-         "valu_wave_instr_per_launch": valu,
+         "valu_wave_instr_per_step": valu,
          "frac_of_measured_mix_ceiling": achieved / VALU_MIX_CEILING if achieved else None,
          "mfma": None,
          "hbm_equivalent": {"achieved_GBs": hbm_eq, "x_hbm_peak": hbm_eq / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
@@ -402,10 +402,12 @@ def roofline(rec, wl, pmc, sha):
          "pmc_source": p.get("source") if fresh else None,
          "pmc_kernel_src_sha": p.get("kernel_src_sha"), "kernel_src_sha": sha,
          "note": "peak = 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md); "
-                 "SQ_INSTS_VALU per launch is deterministic for a build + workload and comes from the committed rocprofv3 "
-                 "PMC pass (null when the kernel sources changed since); kernel_ms is this run's HIP-event time"}
+                 "SQ_INSTS_VALU per step (summed over the dominant kernel's launches of a step: at cfg3 the main launch, the "
+                 "column pieces of the rows beyond a full round and their repair launch) is deterministic for a build + "
+                 "workload and comes from the committed rocprofv3 PMC pass (null when the kernel sources changed since); "
+                 "kernel_ms is this run's HIP-event time around all launches of the call"}
     if mfma:
-        r["mfma"] = {"instr_per_launch": mfma, "pipe_busy_frac": mfma * MFMA_I8_CYCLES / (CUS * SIMDS * CLOCK_HZ * rec["kern_ms"] * 1e-3),
+        r["mfma"] = {"instr_per_step": mfma, "pipe_busy_frac": mfma * MFMA_I8_CYCLES / (CUS * SIMDS * CLOCK_HZ * rec["kern_ms"] * 1e-3),
                      "note": "v_mfma_f32_32x32x64_f8f6f4 with FP4 operands (stage-1 signature filter, K = 54 signature bits + 10 bias slots), 32 cycles per instruction per SIMD at 2.4 GHz"}
     if wl["mode"] == "lev":
         r["kernel"] = "pg_lev_* (profile + bag filter pg_nsq_kernel<BagMetric> + pg_lev_select_kernel)"

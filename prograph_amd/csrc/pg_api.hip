@@ -77,16 +77,23 @@ int64_t pg_npad(int64_t n) { return n <= 0 ? 256 : ((n + 255) / 256) * 256; }
 int pg_ngroups(int l) { return l <= 0 ? 1 : (l + 31) / 32; }
 int pg_nchunks(int l, int bits) { return (pg_ngroups(l) * bits + 3) / 4; }
 int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunks(l, bits) * 16 + PG_AUX_BYTES) * pg_npad(n); }
-// launch-private device state of an all-pairs call: today the pass counter of the persistent waves (one word in a
-// 64-byte line of its own); sized by the row count so that later per-row state needs no ABI change
-// [0, 64) the pass counter, [64, 128) the probe's decision words (gates), [128, 128 + 8 * PG_PROBE_ROWS * PG_PROBE_WAVES) its counts
-// from PG_WS_PARTIAL on: the lists of the column pieces (knn_launch: the rows one full round of waves cannot hold) -
-// at most PG_SPLIT_MAX_ROWS rows x 8 pieces (or half of them x 16) x PG_MM_KL keys
-#define PG_WS_PARTIAL (128 + 8 * 64 * 128)
+// launch-private device state of an all-pairs call, sized by the row count:
+//   [0, 64)      pass counters of the engine's persistent waves (words 0, 4, 8, 12: a call's main launch, its column
+//                pieces, its gated 32-row alternative, its repair launch)
+//   [64, 576)    one flag word per row block of a launch in column pieces (knn_launch)     - zeroed with the counters
+//   [576, 640)   the probe's decision words (gates)
+//   [640, ...)   the probe's counts (8 * PG_PROBE_ROWS * PG_PROBE_WAVES bytes)
+//   from PG_WS_PARTIAL on, launches of more than PG_SPLIT_MIN_ROWS rows: the lists of the column pieces - at most
+//                PG_SPLIT_MAX_ROWS rows x 8 pieces (or half of them x 16) x PG_MM_KL keys
+#define PG_WS_FLAGS 64
+#define PG_WS_GATES 576
+#define PG_WS_COUNTS 640
+#define PG_WS_PARTIAL (PG_WS_COUNTS + 8 * 64 * 128)
 #define PG_SPLIT_MAX_ROWS 8192
 #define PG_SPLIT_MIN_ROWS 131072    // (launches below never split)
+static_assert(PG_WS_GATES - PG_WS_FLAGS >= 4 * (PG_SPLIT_MAX_ROWS / (2 * PG_MM_RB)), "one flag word per 64-row block");
 int64_t pg_workspace_bytes(int64_t nrows) {
-  return PG_WS_PARTIAL + (nrows > PG_SPLIT_MIN_ROWS ? (int64_t)PG_SPLIT_MAX_ROWS * 8 * PG_MM_KL * 4 + 4 * (PG_SPLIT_MAX_ROWS / (2 * PG_MM_RB)) : 0);
+  return PG_WS_PARTIAL + (nrows > PG_SPLIT_MIN_ROWS ? (int64_t)PG_SPLIT_MAX_ROWS * 8 * PG_MM_KL * 4 : 0);
 }
 
 }  // extern "C"
@@ -416,36 +423,48 @@ __global__ __launch_bounds__(1024) void pg_decide_kernel(const u32 *counts, int 
     gate[1] = force >= 0 ? (u32)((force >> 1) & 1) : (eps * 25ull > (unsigned long long)nsample * (unsigned long long)ncols ? 1u : 0u);
   }
 }
-// kNN of rows swept in column pieces (NsqParams::mmPieces): a row's `pieces` lists of k + 1 keys each -> its k + 1
-// smallest keys, ranks 1..k written out (the reference drops sorted rank 0, prograph/prograph.py:761-763).  One wave per
-// row; a key's rank = the keys below it (keys are distance << 24 | column: unique, except 0xFFFFFFFF = no entry).
+// kNN of rows swept in column pieces (NsqParams::mmPieces): a row's `pieces` (<= 16) sorted lists of k + 1 keys each -> its
+// k + 1 smallest keys, ranks 1..k written out (the reference drops sorted rank 0, prograph/prograph.py:761-763).  Sixteen
+// lanes per row, lane b holds the head of list b: k + 1 rounds of "smallest head wins and advances" (keys are
+// distance << 24 | column: unique, except 0xFFFFFFFF = no entry).  Four rows per wave.
 // A piece's list is exact below the optimistic cap only (NsqParams::mmPieces): a row whose merged (k+1)-th distance is
 // not below `cap` flags its block of `blockRows` rows for the repair launch.
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_knn_merge_kernel(const u32 *partial, long long nrows, int pieces, int k, int *idx,
                                                                      unsigned char *dist, u32 cap, int blockRows, u32 *blockFlags,
                                                                      const u32 *gate, u32 gateWant) {
-  __shared__ u32 keys[PG_WG_WAVES][16 * PG_MM_KL];
+  __shared__ u32 keys[PG_WG_WAVES][4][16 * PG_MM_KL];
   if (gate && __builtin_nontemporal_load(gate) != gateWant) return;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long long row = (long long)blockIdx.x * PG_WG_WAVES + wv;
-  if (row >= nrows) return;                                // (whole wave; no workgroup barrier below)
-  const int n = pieces * (k + 1);
-  for (int e = lane; e < n; e += 64) keys[wv][e] = partial[row * n + e];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, b = lane & 15;
+  const long long row0 = ((long long)blockIdx.x * PG_WG_WAVES + wv) * 4;
+  if (row0 >= nrows) return;                               // (whole wave; no workgroup barrier below)
+  const int k1 = k + 1, n = pieces * k1;
+  for (int r = 0; r < 4; ++r)
+    if (row0 + r < nrows)
+      for (int e = lane; e < n; e += 64) keys[wv][r][e] = partial[(row0 + r) * n + e];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int e = lane; e < n; e += 64) {
-    const u32 key = keys[wv][e];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const u32 kj = keys[wv][j];
-      rank += (kj < key || (kj == key && j < e)) ? 1 : 0;
+  const long long row = row0 + g;
+  const bool mine = row < nrows && b < pieces;
+  int pos = 0;
+  u32 head = mine ? keys[wv][g][b * k1] : 0xFFFFFFFFu;
+  for (int r = 0; r <= k; ++r) {
+    u32 m = head;
+    for (int o = 8; o > 0; o >>= 1) {
+      const u32 x = (u32)__shfl_xor((int)m, o, 16);
+      m = x < m ? x : m;
     }
-    if (rank >= 1 && rank <= k) {
-      idx[row * k + rank - 1] = key == 0xFFFFFFFFu ? -1 : (int)(key & 0x00FFFFFFu);
-      dist[row * k + rank - 1] = (unsigned char)(key >> 24);
+    if (b == 0 && row < nrows) {
+      if (r >= 1) {
+        idx[row * k + r - 1] = m == 0xFFFFFFFFu ? -1 : (int)(m & 0x00FFFFFFu);
+        dist[row * k + r - 1] = (unsigned char)(m >> 24);
+      }
+      if (r == k && (m >> 24) >= cap) blockFlags[row / blockRows] = 1u;   // (0xFFFFFFFF, no entry, reads 255)
     }
-    if (rank == k && (key >> 24) >= cap) blockFlags[row / blockRows] = 1u;   // (0xFFFFFFFF, no entry, reads 255)
+    if (mine && head == m && m != 0xFFFFFFFFu) {           // the winner (unique key) moves on in its list
+      ++pos;
+      head = pos < k1 ? keys[wv][g][b * k1 + pos] : 0xFFFFFFFFu;
+    }
   }
 }
 
@@ -461,8 +480,8 @@ static bool probe_enabled() {
 static int run_probe(const NsqParams &e, int l, int bits, u32 near, u32 lo, u32 span, u32 need, void *workspace, hipStream_t s,
                      const u32 **gate) {
   if (!workspace) return fail(PG_E_BADARG, "workspace required (pg_workspace_bytes)");
-  u32 *gates = (u32 *)((char *)workspace + 64), *counts = (u32 *)((char *)workspace + 128);
-  static_assert(128 + 8 * PG_PROBE_ROWS * PG_PROBE_WAVES <= 128 + 8 * 64 * 128, "pg_workspace_bytes");
+  u32 *gates = (u32 *)((char *)workspace + PG_WS_GATES), *counts = (u32 *)((char *)workspace + PG_WS_COUNTS);
+  static_assert(PG_WS_COUNTS + 8 * PG_PROBE_ROWS * PG_PROBE_WAVES <= PG_WS_PARTIAL, "pg_workspace_bytes");
   ProbeParams pp;
   pp.rowPlanes = e.rowPlanes; pp.colPlanes = e.colPlanes; pp.rowNpad = e.rowNpad; pp.colNpad = e.colNpad;
   pp.row0 = e.row0; pp.nrows = e.nrows; pp.ncols = e.ncols;
@@ -764,7 +783,7 @@ static void plan_mm(int64_t nrows, NsqParams *p, int *grid, int rb = PG_MM_RB, i
 static int pass_counter(NsqParams *p, void *workspace, hipStream_t s) {
   if (!workspace) return fail(PG_E_BADARG, "workspace required (pg_workspace_bytes)");
   unsigned *c = (unsigned *)workspace;
-  const hipError_t e = hipMemsetAsync(c, 0, 64, s);        // (two counters: words 0 and 8 - a launch's gated alternative has its own)
+  const hipError_t e = hipMemsetAsync(c, 0, PG_WS_GATES, s);   // (the counters and the row-block flags of a launch in column pieces)
   if (e != hipSuccess) return hipfail(e, "workspace: hipMemsetAsync");
   p->mmPassCounter = c;
   return 0;
@@ -999,9 +1018,8 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
       q.mmPassCounter = p.mmPassCounter + 4;
       if (int rc = launched(kMm[ng - 1](PG_MODE_KNN_SHORT2, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn)")) return rc;
       if (int rc = launched(kMm[ng - 1](PG_MODE_KNN_SHORT2, bits, q, (int)(q.mmGridWaves / PG_WG_WAVES), (hipStream_t)stream), "pg_mm_kernel(knn, column pieces)")) return rc;
-      u32 *flags = (u32 *)((char *)workspace + PG_WS_PARTIAL + (size_t)PG_SPLIT_MAX_ROWS * 8 * PG_MM_KL * 4);   // one word per row block
-      if (hipError_t e = hipMemsetAsync(flags, 0, (size_t)nb * 4, (hipStream_t)stream); e != hipSuccess) return hipfail(e, "workspace: hipMemsetAsync");
-      pg_knn_merge_kernel<<<dim3((unsigned)((rem + PG_WG_WAVES - 1) / PG_WG_WAVES)), dim3(PG_WG_THREADS), 0, (hipStream_t)stream>>>(
+      u32 *flags = (u32 *)((char *)workspace + PG_WS_FLAGS);   // one word per row block (zeroed with the counters)
+      pg_knn_merge_kernel<<<dim3((unsigned)((rem + 4 * PG_WG_WAVES - 1) / (4 * PG_WG_WAVES))), dim3(PG_WG_THREADS), 0, (hipStream_t)stream>>>(
           q.mmPartial, rem, pieces, k, idx_out + mainRows * k, dist_out + mainRows * k, p.knnGuess, 2 * PG_MM_RB, flags, p.gate, p.gateWant);
       if (int rc = launched((int)hipGetLastError(), "pg_knn_merge_kernel")) return rc;
       // the repair launch: the same rows in plain 64-row passes, the blocks the merge did not flag skipped

@@ -19,15 +19,15 @@ for wl in wls:
     if os.path.exists(b):
         shutil.copy(b, os.path.join(root, "profiles", f"{tag}_bench_{wl}.json"))
     pmc[wl] = {
-        "hbm_bytes_per_launch": summ.get("hbm_bytes_per_launch"),
+        "hbm_bytes_per_step": summ.get("hbm_bytes_per_step"),
         "kernel_avg_ns": summ["kernel"]["avg_ns"],
         "kernel_name": summ["kernel"]["name"][:60],
         "kernel_src_sha": summ.get("kernel_src_sha"),
         "valu_issue_frac": summ.get("valu_issue_frac_of_peak"),
-        "valu_wave_instr_per_launch": summ["counters"].get("SQ_INSTS_VALU"),
+        "valu_wave_instr_per_step": summ["counters"].get("SQ_INSTS_VALU"),
         "valu_wave_instr_per_step_all_kernels": summ.get("valu_wave_instr_per_step_all_kernels"),
-        "salu_instr_per_launch": summ["counters"].get("SQ_INSTS_SALU"),
-        "mfma_instr_per_launch": summ["counters"].get("SQ_INSTS_MFMA"),
+        "salu_instr_per_step": summ["counters"].get("SQ_INSTS_SALU"),
+        "mfma_instr_per_step": summ["counters"].get("SQ_INSTS_MFMA"),
         "wait_any_frac_of_wave_cycles": (summ["counters"].get("SQ_WAIT_ANY", 0) / summ["counters"]["SQ_WAVE_CYCLES"]) if summ["counters"].get("SQ_WAVE_CYCLES") else None,
         "clock_ghz": summ.get("clock_ghz"),
         "l2_hit_rate": summ.get("l2_hit_rate"),
