@@ -89,8 +89,8 @@ int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunk
 #define PG_WS_GATES 576
 #define PG_WS_COUNTS 640
 #define PG_WS_PARTIAL (PG_WS_COUNTS + 8 * 64 * 128)
-#define PG_SPLIT_MAX_ROWS 8192
-#define PG_SPLIT_MIN_ROWS 131072    // (launches below never split)
+#define PG_SPLIT_MAX_ROWS 8192       // 128 row blocks of 64
+#define PG_SPLIT_MIN_ROWS 65536     // (launches up to here never split)
 static_assert(PG_WS_GATES - PG_WS_FLAGS >= 4 * (PG_SPLIT_MAX_ROWS / (2 * PG_MM_RB)), "one flag word per 64-row block");
 int64_t pg_workspace_bytes(int64_t nrows) {
   return PG_WS_PARTIAL + (nrows > PG_SPLIT_MIN_ROWS ? (int64_t)PG_SPLIT_MAX_ROWS * 8 * PG_MM_KL * 4 : 0);
@@ -986,49 +986,57 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     const int occ2 = shortList ? mm_occupancy(ng, PG_MODE_KNN_SHORT2, bits) : 0;
     bool two = shortList && (nrows + PG_MM_RB - 1) / PG_MM_RB > slots1 && occ2 >= 3;
     if (const char *e = getenv("PG_MM_R")) two = shortList && atoi(e) == 2;
-    // One wave more on every SIMD for a few rows more costs the launch as much as a full round of them (plan_mm).
-    // Rows that one round of waves fewer holds go first; the few beyond - at most PG_SPLIT_MAX_ROWS - follow in a launch
-    // of their own where every pass sweeps one PIECE of the columns (as many pieces as give every SIMD about one
-    // wave: short passes, a sixteenth or an eighth of a sweep each), and pg_knn_merge_kernel makes the rows' lists of the pieces'.
+    // One wave more on every SIMD for a few rows more costs the launch as much as a full round of them (plan_mm), and
+    // so does a last round of the persistent waves that only a few passes are left for.  The rows that whole rounds
+    // hold go first; the few beyond - at most 128 row blocks - follow in a launch of their own where every pass sweeps
+    // one PIECE of the columns (as many pieces as give every SIMD about one wave: short passes, a sixteenth or an
+    // eighth of a sweep each), and pg_knn_merge_kernel makes the rows' lists of the pieces'.
     // cfg3 (200 000 rows = 3 x 65 536 + 3 392): three waves per SIMD + 53 row blocks x 16 pieces.  PG_MM_SPLIT=0: off
+    const int rbm = two ? 2 * PG_MM_RB : PG_MM_RB, occm = two ? occ2 : occ1;
+    const int modeM = two ? PG_MODE_KNN_SHORT2 : (shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN);
     long long mainRows = nrows;
-    if (two && workspace && p.knnGuess > 0 && ncols >= 65536 && nrows > PG_SPLIT_MIN_ROWS && !getenv("PG_ROWS_PER_WAVE") &&
+    if (shortList && workspace && p.knnGuess > 0 && ncols >= 65536 && nrows > PG_SPLIT_MIN_ROWS && !getenv("PG_ROWS_PER_WAVE") &&
         !(getenv("PG_MM_SPLIT") && atoi(getenv("PG_MM_SPLIT")) == 0)) {
-      const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4, rb2 = 2 * PG_MM_RB;
-      const long long w = ((nrows + rb2 - 1) / rb2 + simds - 1) / simds;
-      const long long held = (w - 1) * simds * rb2;
-      if (w >= 3 && w <= occ2 && nrows - held <= PG_SPLIT_MAX_ROWS) mainRows = held;
+      const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4;
+      const long long passes = (nrows + rbm - 1) / rbm, slots = simds * occm;
+      long long held = 0;
+      if (passes <= slots) {                                // one round: one wave fewer per SIMD
+        const long long w = (passes + simds - 1) / simds;
+        if (w >= 3) held = (w - 1) * simds * rbm;
+      } else {                                              // several: whole rounds of full occupancy
+        held = nrows / (slots * rbm) * (slots * rbm);
+      }
+      if (held > 0 && nrows - held <= 128ll * rbm) mainRows = held;
     }
-    plan_mm(mainRows, &p, &grid, two ? 2 * PG_MM_RB : PG_MM_RB, two ? occ2 : occ1, true);
+    plan_mm(mainRows, &p, &grid, rbm, occm, true);
     p.nrows = mainRows;
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
     if (mainRows < nrows) {
       NsqParams q = p;
-      const long long rem = nrows - mainRows, nb = (rem + 2 * PG_MM_RB - 1) / (2 * PG_MM_RB);
+      const long long rem = nrows - mainRows, nb = (rem + rbm - 1) / rbm;
       const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4;
-      int pieces = (int)(simds / nb);
+      int pieces = (int)(simds / nb);                       // (nb <= 128: at least 8; nb * pieces <= 1024 passes = the workspace's share)
       pieces = pieces > 16 ? 16 : (pieces < 2 ? 2 : pieces);
-      if (const char *e = getenv("PG_MM_PIECES")) { if (atoi(e) >= 2 && atoi(e) <= 16) pieces = atoi(e); }   // (experiments)
-      if (rem > PG_SPLIT_MAX_ROWS / 2 && pieces > 8) pieces = 8;        // (the workspace holds 8 pieces of 8192 rows or 16 of 4096)
+      if (const char *e = getenv("PG_MM_PIECES")) { if (atoi(e) >= 2 && atoi(e) <= (nb <= 64 ? 16 : 8)) pieces = atoi(e); }   // (experiments)
       q.row0 = p.row0 + mainRows; q.nrows = rem;
-      q.rowsPerWave = 2 * PG_MM_RB; q.rowsPerPass = 2 * PG_MM_RB; q.mmTailFrom = nb; q.mmTailRows = 2 * PG_MM_RB;
+      q.rowsPerWave = rbm; q.rowsPerPass = rbm; q.mmTailFrom = nb; q.mmTailRows = rbm;
       q.mmPieces = pieces; q.mmPartial = (u32 *)((char *)workspace + PG_WS_PARTIAL);
       q.mmPasses = nb * pieces;
       q.mmGridWaves = (q.mmPasses + PG_WG_WAVES - 1) / PG_WG_WAVES * PG_WG_WAVES;   // (one wave per pass: fewer than the chip's slots)
       q.mmPassCounter = p.mmPassCounter + 4;
-      if (int rc = launched(kMm[ng - 1](PG_MODE_KNN_SHORT2, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn)")) return rc;
-      if (int rc = launched(kMm[ng - 1](PG_MODE_KNN_SHORT2, bits, q, (int)(q.mmGridWaves / PG_WG_WAVES), (hipStream_t)stream), "pg_mm_kernel(knn, column pieces)")) return rc;
+      if (int rc = launched(kMm[ng - 1](modeM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn)")) return rc;
+      if (int rc = launched(kMm[ng - 1](modeM, bits, q, (int)(q.mmGridWaves / PG_WG_WAVES), (hipStream_t)stream), "pg_mm_kernel(knn, column pieces)")) return rc;
       u32 *flags = (u32 *)((char *)workspace + PG_WS_FLAGS);   // one word per row block (zeroed with the counters)
       pg_knn_merge_kernel<<<dim3((unsigned)((rem + 4 * PG_WG_WAVES - 1) / (4 * PG_WG_WAVES))), dim3(PG_WG_THREADS), 0, (hipStream_t)stream>>>(
-          q.mmPartial, rem, pieces, k, idx_out + mainRows * k, dist_out + mainRows * k, p.knnGuess, 2 * PG_MM_RB, flags, p.gate, p.gateWant);
+          q.mmPartial, rem, pieces, k, idx_out + mainRows * k, dist_out + mainRows * k, p.knnGuess, rbm, flags, p.gate, p.gateWant);
       if (int rc = launched((int)hipGetLastError(), "pg_knn_merge_kernel")) return rc;
-      // the repair launch: the same rows in plain 64-row passes, the blocks the merge did not flag skipped
+      // the repair launch: the same rows in plain passes, the blocks the merge did not flag skipped
       NsqParams f = q;
       f.mmPieces = 0; f.mmPartial = nullptr; f.mmBlockFlags = flags;
       f.mmPasses = nb; f.mmGridWaves = (nb + PG_WG_WAVES - 1) / PG_WG_WAVES * PG_WG_WAVES;
       f.mmPassCounter = p.mmPassCounter + 12;
       f.knnIdx = idx_out + mainRows * k; f.knnDist = dist_out + mainRows * k;
-      if (int rc = launched(kMm[ng - 1](PG_MODE_KNN_SHORT2, bits, f, (int)(f.mmGridWaves / PG_WG_WAVES), (hipStream_t)stream), "pg_mm_kernel(knn, repair)")) return rc;
+      if (int rc = launched(kMm[ng - 1](modeM, bits, f, (int)(f.mmGridWaves / PG_WG_WAVES), (hipStream_t)stream), "pg_mm_kernel(knn, repair)")) return rc;
       p.nrows = nrows;                                      // (the gated 32-row alternative below covers all rows)
     }
     if (two && p.gate && !getenv("PG_MM_R")) {

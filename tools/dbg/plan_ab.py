@@ -10,7 +10,7 @@ def timeit(f, iters=7):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return float(np.median(ts))
-for N, L, bits in ((20000, 32, 5), (50000, 32, 5), (50000, 64, 5), (100000, 128, 5), (100000, 64, 5), (150000, 64, 5), (180000, 64, 5), (200000, 64, 5), (200000, 64, 8), (100000, 64, 8), (300000, 64, 5)):
+for N, L, bits in ((100000, 128, 5), (100000, 64, 5), (140000, 64, 5), (200000, 64, 5), (200000, 64, 8), (100000, 64, 8), (270000, 64, 5), (300000, 64, 5)):
     tok = synth.clustered_tokens(N, L)
     p = nat.pack(torch.from_numpy(tok), bits=bits); dev = p.buf.device; cap = 256
     si = torch.empty(N * cap, dtype=torch.int32, device=dev); sw = torch.empty(N * cap, dtype=torch.uint8, device=dev)
@@ -24,7 +24,7 @@ for N, L, bits in ((20000, 32, 5), (50000, 32, 5), (50000, 64, 5), (100000, 128,
     for name, f in (("knn", knn),):
         best = {}
         for rnd in range(3):
-            for label, env in (("new", {}), ("old", {"PG_MM_PLAN": "2"}), ("rpw64/R2", {"PG_ROWS_PER_WAVE": "64", "PG_MM_R": "2"}), ("rpw32/R1", {"PG_ROWS_PER_WAVE": "32", "PG_MM_R": "1"})):
+            for label, env in (("new", {}), ("no split", {"PG_MM_SPLIT": "0"}), ("old plan", {"PG_MM_PLAN": "2", "PG_MM_SPLIT": "0"})):
                 os.environ.update(env); t = timeit(f)
                 for k_ in env: os.environ.pop(k_)
                 best[label] = min(best.get(label, 1e9), t)
