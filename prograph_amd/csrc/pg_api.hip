@@ -1012,27 +1012,30 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     p.nrows = mainRows;
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
     if (mainRows < nrows) {
-      NsqParams q = p;
+      NsqParams q;
       const long long rem = nrows - mainRows, nb = (rem + rbm - 1) / rbm;
       const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4;
       int pieces = (int)(simds / nb);                       // (nb <= 128: at least 8; nb * pieces <= 1024 passes = the workspace's share)
       pieces = pieces > 16 ? 16 : (pieces < 2 ? 2 : pieces);
       if (const char *e = getenv("PG_MM_PIECES")) { if (atoi(e) >= 2 && atoi(e) <= (nb <= 64 ? 16 : 8)) pieces = atoi(e); }   // (experiments)
+      // the pieces ride in the main launch: its passes beyond the plain ones, fetched through the counter by the waves
+      // that finish first - they run while the slower passes are still at work
+      const long long mainPasses = p.mmPasses;              // (plain passes of rbm rows: plan_mm gave whole rounds)
+      p.nrows = nrows;
+      p.mmPieces = pieces; p.mmPieceFrom = mainPasses; p.mmPartial = (u32 *)((char *)workspace + PG_WS_PARTIAL);
+      p.mmPasses = mainPasses + nb * pieces;
+      p.mmTailFrom = p.mmPasses; p.mmTailRows = rbm;
+      if (int rc = launched(kMm[ng - 1](modeM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn + column pieces)")) return rc;
+      q = p;
       q.row0 = p.row0 + mainRows; q.nrows = rem;
-      q.rowsPerWave = rbm; q.rowsPerPass = rbm; q.mmTailFrom = nb; q.mmTailRows = rbm;
-      q.mmPieces = pieces; q.mmPartial = (u32 *)((char *)workspace + PG_WS_PARTIAL);
-      q.mmPasses = nb * pieces;
-      q.mmGridWaves = (q.mmPasses + PG_WG_WAVES - 1) / PG_WG_WAVES * PG_WG_WAVES;   // (one wave per pass: fewer than the chip's slots)
-      q.mmPassCounter = p.mmPassCounter + 4;
-      if (int rc = launched(kMm[ng - 1](modeM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn)")) return rc;
-      if (int rc = launched(kMm[ng - 1](modeM, bits, q, (int)(q.mmGridWaves / PG_WG_WAVES), (hipStream_t)stream), "pg_mm_kernel(knn, column pieces)")) return rc;
       u32 *flags = (u32 *)((char *)workspace + PG_WS_FLAGS);   // one word per row block (zeroed with the counters)
       pg_knn_merge_kernel<<<dim3((unsigned)((rem + 4 * PG_WG_WAVES - 1) / (4 * PG_WG_WAVES))), dim3(PG_WG_THREADS), 0, (hipStream_t)stream>>>(
-          q.mmPartial, rem, pieces, k, idx_out + mainRows * k, dist_out + mainRows * k, p.knnGuess, rbm, flags, p.gate, p.gateWant);
+          p.mmPartial, rem, pieces, k, idx_out + mainRows * k, dist_out + mainRows * k, p.knnGuess, rbm, flags, p.gate, p.gateWant);
       if (int rc = launched((int)hipGetLastError(), "pg_knn_merge_kernel")) return rc;
       // the repair launch: the same rows in plain passes, the blocks the merge did not flag skipped
       NsqParams f = q;
-      f.mmPieces = 0; f.mmPartial = nullptr; f.mmBlockFlags = flags;
+      f.mmPieces = 0; f.mmPieceFrom = 0; f.mmPartial = nullptr; f.mmBlockFlags = flags;
+      f.rowsPerWave = rbm; f.rowsPerPass = rbm; f.mmTailFrom = nb; f.mmTailRows = rbm;
       f.mmPasses = nb; f.mmGridWaves = (nb + PG_WG_WAVES - 1) / PG_WG_WAVES * PG_WG_WAVES;
       f.mmPassCounter = p.mmPassCounter + 12;
       f.knnIdx = idx_out + mainRows * k; f.knnDist = dist_out + mainRows * k;
@@ -1043,6 +1046,7 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
       // the probe may say "one cluster" (gate 2): the same engine with 32-row passes, launched as a third alternative
       NsqParams q = p;
       int qgrid = 0;
+      q.mmPieces = 0; q.mmPieceFrom = 0; q.mmPartial = nullptr;
       plan_mm(nrows, &q, &qgrid, PG_MM_RB, occ1, true);
       q.mmPassCounter = p.mmPassCounter + 8;
       q.gateWant = 2u;

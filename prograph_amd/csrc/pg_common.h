@@ -290,15 +290,17 @@ struct NsqParams {
   int mmTailRows;
   long long mmPasses, mmGridWaves;   // pg_mm.h: passes in all; waves in the grid (wave w starts with pass w, then takes
   unsigned *mmPassCounter;           // mmGridWaves + atomicAdd(counter) until none is left); the counter starts at 0
-  // pg_mm.h, short-list kNN instances: column pieces.  mmPieces > 1: pass = row block * mmPieces + piece, a pass sweeps
-  // only its piece of the super-tiles and leaves its list (k + 1 keys) in mmPartial[(row * mmPieces + piece) * (k + 1)];
+  // pg_mm.h, short-list kNN instances: column pieces.  mmPieces > 1: pass mmPieceFrom + b * mmPieces + piece sweeps only its
+  // piece of the super-tiles for row block mmPieceFrom + b and leaves its list (k + 1 keys) in mmPartial[(row' * mmPieces + piece) * (k + 1)],
+  // row' counted from the first row in pieces;
   // pg_knn_merge_kernel makes the rows' results of them.  (The rows one full round of waves cannot hold, pg_api.hip.)
   // A piece never gives up the optimistic cap (no checkpoints, no second phase): its list is exact for every column
   // below the cap, so a merged list whose (k+1)-th distance ends below the cap is exact; the merge flags the row
   // blocks where a row's does not (mmBlockFlags[block] = 1), and a third launch - the plain kernel over the same
   // rows, passes whose flag is 0 skipped - sweeps those blocks again in full.
   int mmPieces;
-  u32 *mmPartial;
+  long long mmPieceFrom;            // passes from this index on are column pieces (the ones before: plain passes of rowsPerWave rows)
+  u32 *mmPartial;                   // ... of the rows from mmPieceFrom * rowsPerWave on
   const u32 *mmBlockFlags;          // != null: pass i runs only if mmBlockFlags[i] != 0
   int mmDenseL1, mmDenseL2, mmDirectRun;   // pg_mm.h: density rules of the filter hierarchy
   // data-driven choice between engines / paths WITHOUT a host round trip (pg_api.hip: probe): when `gate` is not

@@ -183,10 +183,10 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         continue;
       }
     }
-    // (column pieces, kPar instances: pass = row block * pieces + piece; uniform passes of rowsPerWave rows)
-    const int npieces = kPar && p.mmPieces > 1 ? p.mmPieces : 1;
-    const long long rpass = npieces > 1 ? pass / npieces : pass;
-    const int piece = npieces > 1 ? (int)(pass - rpass * npieces) : 0;
+    // (column pieces, kPar instances: passes from mmPieceFrom on; uniform passes of rowsPerWave rows)
+    const int npieces = kPar && p.mmPieces > 1 && pass >= p.mmPieceFrom ? p.mmPieces : 1;
+    const long long rpass = npieces > 1 ? p.mmPieceFrom + (pass - p.mmPieceFrom) / npieces : pass;
+    const int piece = npieces > 1 ? (int)((pass - p.mmPieceFrom) % npieces) : 0;
     const bool tailPass = rpass >= p.mmTailFrom;
     const long long prows = tailPass ? p.mmTailRows : p.rowsPerWave;
     const long long pr0 = tailPass ? p.mmTailFrom * p.rowsPerWave + (rpass - p.mmTailFrom) * p.mmTailRows : rpass * p.rowsPerWave;
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           const int k1 = kk + 1;
           for (int e = lane; e < nr * k1; e += 64) {
             const int rr = e / k1, j = e - rr * k1;
-            kr.mmPartial[((pr0 + rr) * (long long)npieces + piece) * k1 + j] = lstbuf[wv][rr][KL - k1 + j];
+            kr.mmPartial[((pr0 - kr.mmPieceFrom * kr.rowsPerWave + rr) * (long long)npieces + piece) * k1 + j] = lstbuf[wv][rr][KL - k1 + j];
           }
         } else
         // the pass's nr x k results are one contiguous stretch of the output: coalesced stores
