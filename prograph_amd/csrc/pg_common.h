@@ -32,11 +32,12 @@ enum { PG_MODE_EPS = 0, PG_MODE_KNN = 1, PG_MODE_EPS_SYM = 2 };   // EPS_SYM: sq
 // ---------------------------------------------------------------------------------------
 // Mismatch counting on the BIT-SLICED layout.
 //
-// Integer VALU instructions issue at one wave64 instruction per 4 cycles per SIMD on gfx950
-// (rocprofv3: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU in quad-cycles), so the all-pairs kernel is
-// bound by VALU instruction count, not by bytes: the first version of this kernel (byte tokens,
-// xor/add/and/popcount, 7 ops per 12 tokens) already sat at 78 % of that issue rate.  The way
-// down is fewer instructions per token:
+// The all-pairs kernels are bound by VALU instruction count, not by bytes.  A SIMD-32 issues a wave64
+// instruction in 2 cycles at best (MI355X_MICROARCH.md: the peak bench.py prices against); measured here
+// (profiles/r01_valu_issue_microbench.txt) v_xor / v_or / v_bitop3 on VGPR operands take 2.4-2.9 cycles, v_or3 /
+// v_bcnt / v_alignbit and anything with an SGPR source 4.2-4.4.  The first version of this kernel (byte tokens,
+// xor/add/and/popcount, 7 ops per 12 tokens) already sat at 78 % of the 4-cycle rate.  The way down is fewer
+// instructions per token:
 //
 //   a sequence is stored as G = ceil(L/32) groups of B bit planes; plane p of group g is one
 //   dword whose bit j is bit p of token 32g+j.  Record order is PLANE MAJOR (dword p*G + g), so

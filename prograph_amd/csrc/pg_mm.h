@@ -102,8 +102,11 @@ __device__ __forceinline__ int pg_or16(const pg_v16i &d) {
   return a | e;
 }
 
-// Records of up to three chunks (L <= 64 with 5 bit planes): held at 4 waves per SIMD (the kNN instance
-// would take 141 VGPRs; pinned to 128 it spills 7 of them outside the loops, measured faster)
+// Records of up to three chunks (L <= 64 with 5 bit planes): held at 4 waves per SIMD (amdgpu_waves_per_eu(4, 8) =
+// 128 VGPRs).  What the compiler reports per instance (-Rpass-analysis=kernel-resource-usage) is committed in
+// profiles/r03_kernel_resource_usage.txt: the 64-row kNN instance takes all 128 and spills 5 VGPRs (24 B per lane of
+// scratch) in the slow paths; tools/check_ring_asm.py checks on the generated ISA that nothing - no spill, no copy - touches
+// a fragment register between its load and the wait in front of the MFMA.
 // KL (kNN only): entries of a row's list in LDS.  64 = the list lives across the wave's lanes (lane j = j-th smallest
 // key; insertion = one DPP shift, one candidate at a time).  KL < 64 (k + 1 <= KL, PG_MM_KL): the list is KL consecutive
 // dwords, RIGHT aligned (the (k+1)-th smallest key, i.e. the row's threshold, is always entry KL-1; unused entries in

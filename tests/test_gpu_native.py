@@ -22,7 +22,7 @@ BITS = [5, 8]
 
 def pytest_generate_tests(metafunc):
     """Tests that reach an all-pairs engine run on both of them: pg_nsq.h (stage 1 on the VALU) and pg_mm.h
-    (stage 1 on the matrix cores) - left alone the library picks by size (MFMA from 40 000 / 60 000 rows on).
+    (stage 1 on the matrix cores) - left alone the library picks by size (MFMA from 20 000 rows for kNN, 40 000 / 60 000 for eps) and, for large launches, by a probe of the data.
     Tests marked `one_engine` (no all-pairs launch, or they choose the engine themselves) run once."""
     if "engine" in metafunc.fixturenames:
         once = metafunc.definition.get_closest_marker("one_engine") is not None
