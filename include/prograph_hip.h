@@ -14,7 +14,9 @@
  *     storage container); the library never allocates or frees device memory and never
  *     synchronises.  The all-pairs calls (pg_eps_slots[_sym], pg_eps_fill_rows,
  *     pg_knn_hamming[_round]) take a caller-owned `workspace` of pg_workspace_bytes(nrows)
- *     bytes: launch-private device state (the pass counter of the engine's persistent waves),
+ *     bytes: launch-private device state (the pass counters of the engine's persistent waves,
+ *     the data probe's counts and decision words, and - kNN calls of more than 65 536 rows,
+ *     5.2 MB - the partial neighbour lists of rows swept in column pieces),
  *     initialised by the call on `stream`; ONE workspace per launch in flight - a workspace
  *     may be reused once the launch that got it has completed, or by later launches on the
  *     same stream;
