@@ -511,7 +511,7 @@ class Prograph:
                 tuples = g.to_tuples()
             self.csr_graphs[_keep] = g
             # the device CSR answers for the column only while the column still holds THESE row objects
-            self._csr_rows[_keep] = (tuples[0], tuples[len(tuples) // 2], tuples[-1]) if tuples else ()
+            self._csr_rows[_keep] = self._row_ids(tuples)
         if output == "csr":
             return g
         return tuples if tuples is not None else g.to_tuples()
@@ -672,7 +672,7 @@ class Prograph:
             tuples = g.to_tuples()
             self.graph[name] = tuples
             self.csr_graphs[name] = g
-            self._csr_rows[name] = (tuples[0], tuples[len(tuples) // 2], tuples[-1]) if tuples else ()
+            self._csr_rows[name] = self._row_ids(tuples)
 
     def _device_graph_any(self, graph):
         """The device-resident form (CSRGraph or KNNGraph as built) of a column that still matches it."""
@@ -691,13 +691,29 @@ class Prograph:
             return None
         # identity, not shape: a user who overwrote the column (even with a graph of the same structure,
         # e.g. similarity weights instead of distances) stored other row objects
-        rows = self._csr_rows.get(graph, ())
-        if len(rows) != 3:
+        # (every row up to 262 144 rows - an in-place replacement of ANY row's tuple is seen; 1024 evenly spaced rows beyond,
+        #  where walking a million Python objects would cost more than the device analytics save)
+        keep, ids = self._csr_rows.get(graph, (None, None))
+        if ids is None or len(ids) != len(col):
             return None
-        for r, obj in zip((0, g.nrows // 2, g.nrows - 1), rows):
-            if col.iloc[r] is not obj:
-                return None
+        now = self._row_ids(col.values)[1]
+        pick = slice(None) if len(ids) <= 262144 else np.linspace(0, len(ids) - 1, 1024).astype(np.int64)
+        if not np.array_equal(now[pick], ids[pick]):
+            return None
         return g
+
+    @staticmethod
+    def _row_ids(rows):
+        """(the row objects - kept alive, so their ids stay theirs -, their ids): which tuples a graph column holds.
+        Beyond 262 144 rows only 1024 evenly spaced ones are looked at."""
+        n = len(rows)
+        if n <= 262144:
+            return list(rows), np.fromiter(map(id, rows), dtype=np.int64, count=n)
+        ids = np.zeros(n, dtype=np.int64)
+        pick = np.linspace(0, n - 1, 1024).astype(np.int64)
+        held = [rows[i] for i in pick]
+        ids[pick] = [id(o) for o in held]
+        return held, ids
 
     def _column_csr(self, graph):
         """(indptr, indices, weights) numpy arrays of a Neighbours-style column."""

@@ -235,6 +235,12 @@ def test_matrix_and_degree(pgraph):
         assert np.array_equal(d1, d0) and np.allclose(v1, v0, rtol=1e-9, atol=1e-12) and np.allclose(q1, q0, rtol=1e-9)
         A = pgraph.adjacency(name)
         assert A.shape == (1000, 1000) and A.nnz == len(pgraph.get_neighbour_coords(name)[0])
+    # ONE row's tuple replaced in place - any row, not just the first / middle / last: the device CSR is stale
+    assert pgraph._device_graph("K5") is not None
+    col = pgraph.graph["K5"].values
+    col[337] = (col[337][0], col[337][1] * 3)
+    assert pgraph._device_graph("K5") is None
+    assert pgraph.degree("K5")[337] == col[337][1].sum()       # (the host path reads the column as it is now)
     pgraph.graph["E2"] = pgraph.build_graph(eps=1)           # user overwrites the column: cache must not be used
     assert pgraph._device_graph("E2") is None and np.all(pgraph.degree("E2") == 27)
     # ... also when the new graph has the SAME structure and only other weights (the old check
