@@ -55,6 +55,7 @@ typedef int pg_v16i __attribute__((ext_vector_type(16)));
 #define PG_MM_DENSE_L2 48    // (unused since the MFMA level 2 was dropped; NsqParams still carries the field)
 #define PG_MM_GROUP_ROWS 4    // folded form: rows per group of straight-line code (their folds: 20 SGPRs in flight)
 #define PG_MM_DIRECT_RUN 8   // super-tiles of dense form before the MFMA filter is probed again
+#define PG_MM_PRIO_STEPS 16  // R = 2: steps of the progress-driven issue priority along a sweep
 #ifndef PG_EXP_SAMETILE
 #define PG_EXP_SAMETILE 0   // experiment builds: 1 = every fragment load reads the same super-tile (L1 hits; wrong results)
 #endif
@@ -1040,6 +1041,19 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           continue;
         }
         if (stale) { PG_ST(19, 1); refresh_bias(); }
+        // Issue priority falls with a wave's progress (16 steps along the sweep, the priority cycling 3..0 within four of
+        // them): the waves of a SIMD advance together.  Left alone the arbiter favours the oldest wave, the three waves of
+        // a SIMD finish at 0.70 / 0.83 / 1.0 of the launch (profiles/r03_pass_timeline.txt) and its last third runs with
+        // two, then one wave per SIMD.  cfg3 1.74 -> 1.65 ms, N = 270k 2.62 -> 2.42 (4 steps: 1.69; 64: 1.69); the 32-row
+        // instances do not gain (N = 100k L = 128: 0.98 -> 0.99; N = 50k: 0.50 -> 0.52) and stay as they were.
+        if constexpr (R == 2) {
+          const int step = ((S - sb) * PG_MM_PRIO_STEPS) / (se - sb > 0 ? se - sb : 1);
+          const int pr = step & 3;
+          if (pr == 0) __builtin_amdgcn_s_setprio(3);
+          else if (pr == 1) __builtin_amdgcn_s_setprio(2);
+          else if (pr == 2) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
         const int Sin = S;
         PG_ST(18, 1);
         PG_T0(ts0);
