@@ -1025,6 +1025,13 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
       p.mmPieces = pieces; p.mmPieceFrom = mainPasses; p.mmPartial = (u32 *)((char *)workspace + PG_WS_PARTIAL);
       p.mmPasses = mainPasses + nb * pieces;
       p.mmTailFrom = p.mmPasses; p.mmTailRows = rbm;
+      // ... or, where the chip has slots left beside the plain passes (one round: a wave per SIMD is free), as waves of
+      // their own from the start: short guests at four waves per SIMD instead of a tail of 886 waves on an empty chip
+      // (PG_MM_PIECES_AHEAD=0: through the counter)
+      if (mainPasses + nb * pieces <= simds * occm && !(getenv("PG_MM_PIECES_AHEAD") && atoi(getenv("PG_MM_PIECES_AHEAD")) == 0)) {
+        p.mmGridWaves = (p.mmPasses + PG_WG_WAVES - 1) / PG_WG_WAVES * PG_WG_WAVES;
+        grid = (int)(p.mmGridWaves / PG_WG_WAVES);
+      }
       if (int rc = launched(kMm[ng - 1](modeM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn + column pieces)")) return rc;
       q = p;
       q.row0 = p.row0 + mainRows; q.nrows = rem;

@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         // them): the waves of a SIMD advance together.  Left alone the arbiter favours the oldest wave, the three waves of
         // a SIMD finish at 0.70 / 0.83 / 1.0 of the launch (profiles/r03_pass_timeline.txt) and its last third runs with
         // two, then one wave per SIMD.  cfg3 1.74 -> 1.65 ms, N = 270k 2.62 -> 2.42 (4 steps: 1.69; 64: 1.69); the 32-row
-        // instances do not gain (N = 100k L = 128: 0.98 -> 0.99; N = 50k: 0.50 -> 0.52) and stay as they were.
+        // instances do not gain (N = 100k L = 128: 0.98 -> 0.99; N = 50k: 0.50 -> 0.52), nor do eps launches (3.02 / 3.00 ms): left alone.
         if constexpr (R == 2) {
           const int step = ((S - sb) * PG_MM_PRIO_STEPS) / (se - sb > 0 ? se - sb : 1);
           const int pr = step & 3;
