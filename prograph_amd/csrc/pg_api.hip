@@ -936,6 +936,40 @@ int pg_eps_fill_rows(const void *row_planes, int64_t row_npad, int64_t row0, con
   return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps fill)");
 }
 
+// What a kNN launch of `nrows` rows takes on the 32-row (rb = 32) or the 64-row (rb = 64) short-list instance, in units of
+// "ms per 200 000 columns", from the measured cost of a round of waves (profiles/r03_pass_plan.txt: it follows the waves per
+// SIMD, not the rows per wave), and which rows go into plain passes (*mainRows; the rest: column pieces, knn_launch).
+//   one round   : T(w), w = waves on the busiest SIMD; with w >= 3 and at most 128 row blocks beyond w - 1 full waves:
+//                 T(w - 1) + the pieces
+//   more rounds : whole rounds of full occupancy + (a last round: T(its waves) | at most 128 row blocks: the pieces)
+static double knn_plan_cost(long long nrows, int rb, int occ, bool canSplit, long long *mainRows) {
+  static const double T1[4] = {0.70, 0.79, 0.94, 1.12}, T2[4] = {0.95, 1.22, 1.45, 1.75};
+  const double *T = rb > PG_MM_RB ? T2 : T1, kPieces = 0.08;
+  const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4;
+  occ = occ < 1 ? 1 : (occ > 4 ? 4 : occ);
+  const long long passes = (nrows + rb - 1) / rb, slots = simds * occ, maxRem = 128ll * rb;
+  *mainRows = nrows;
+  if (passes <= slots) {
+    const long long w = (passes + simds - 1) / simds;
+    if (canSplit && w >= 3 && nrows - (w - 1) * simds * rb <= maxRem) {
+      *mainRows = (w - 1) * simds * rb;
+      return T[w - 2] + kPieces;
+    }
+    return T[w - 1];
+  }
+  const long long full = nrows / (slots * rb), rem = nrows - full * slots * rb;
+  double t = (double)full * T[occ - 1];
+  if (rem > 0) {
+    if (canSplit && rem <= maxRem) {
+      *mainRows = full * slots * rb;
+      t += kPieces;
+    } else {
+      t += T[((rem + rb - 1) / rb + simds - 1) / simds - 1];
+    }
+  }
+  return t;
+}
+
 static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, int64_t nrows, const void *col_planes,
                       int64_t col_npad, int64_t ncols, int l, int bits, int k, int first, const uint32_t *floor_keys,
                       uint32_t *last_keys, int32_t *idx_out, uint8_t *dist_out, void *workspace, void *stream) {
@@ -975,39 +1009,29 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     // PG_MM_SHORT=0 keeps the 64-lane lists (A/B runs)
     const bool shortList = first == 1 && k + 1 <= PG_MM_KL && !floor_keys && !last_keys &&
                            !(getenv("PG_MM_SHORT") && atoi(getenv("PG_MM_SHORT")) == 0);
-    // ... with 64 rows per pass (every column fragment feeds two MFMAs: half the vector-memory traffic per pair)
-    // where passes of 64 still fill most of the chip's wave slots; PG_MM_R=1 / 2 forces either
-    // once 32-row passes no longer get a wave slot each (measured, tools/dbg/balance*.py, rows x 200 000 columns: 131 072
-    // rows 1.14 ms against 1.26; 147 456: 1.55 / 1.47; 196 608: 1.84 / 1.57); PG_MM_R=1 / 2 forces either
-    const int ng = pg_ngroups(l);
-    const int occ1 = mm_occupancy(ng, shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN, bits);
-    const long long slots1 = (long long)(cu_count() > 0 ? cu_count() : 256) * 4 * occ1;
-    // (byte alphabets: the 64-row instance holds two waves per SIMD, the 32-row one three - 200k rows 2.47 ms against 2.30)
-    const int occ2 = shortList ? mm_occupancy(ng, PG_MODE_KNN_SHORT2, bits) : 0;
-    bool two = shortList && (nrows + PG_MM_RB - 1) / PG_MM_RB > slots1 && occ2 >= 3;
-    if (const char *e = getenv("PG_MM_R")) two = shortList && atoi(e) == 2;
+    // ... with 64 rows per pass (every column fragment feeds two MFMAs: half the vector-memory traffic per pair) where
+    // that is the cheaper plan (knn_plan_cost; PG_MM_R=1 / 2 forces either).  5-bit L = 64: 64-row passes from 131 073
+    // rows on (131 072 rows 1.14 ms against 1.26; 147 456: 1.55 / 1.47; 196 608: 1.84 / 1.57); L = 128 (three waves per
+    // SIMD) N = 100k: 32-row passes 0.75 against 0.97; byte alphabets (64-row instance: two waves per SIMD): 32-row passes.
     // One wave more on every SIMD for a few rows more costs the launch as much as a full round of them (plan_mm), and
     // so does a last round of the persistent waves that only a few passes are left for.  The rows that whole rounds
-    // hold go first; the few beyond - at most 128 row blocks - follow in a launch of their own where every pass sweeps
-    // one PIECE of the columns (as many pieces as give every SIMD about one wave: short passes, a sixteenth or an
-    // eighth of a sweep each), and pg_knn_merge_kernel makes the rows' lists of the pieces'.
+    // hold go into plain passes; the few beyond - at most 128 row blocks - are swept in PIECES of the columns (as many
+    // pieces as give every SIMD about one wave: short passes, a sixteenth or an eighth of a sweep each), and
+    // pg_knn_merge_kernel makes the rows' lists of the pieces'.
     // cfg3 (200 000 rows = 3 x 65 536 + 3 392): three waves per SIMD + 53 row blocks x 16 pieces.  PG_MM_SPLIT=0: off
+    const int ng = pg_ngroups(l);
+    const int occ1 = mm_occupancy(ng, shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN, bits);
+    const int occ2 = shortList ? mm_occupancy(ng, PG_MODE_KNN_SHORT2, bits) : 0;
+    const bool canSplit = shortList && workspace && p.knnGuess > 0 && ncols >= 65536 && nrows > PG_SPLIT_MIN_ROWS &&
+                          !getenv("PG_ROWS_PER_WAVE") && !(getenv("PG_MM_SPLIT") && atoi(getenv("PG_MM_SPLIT")) == 0);
+    long long main1 = nrows, main2 = nrows;
+    const double t1 = knn_plan_cost(nrows, PG_MM_RB, occ1, canSplit, &main1);
+    const double t2 = shortList ? knn_plan_cost(nrows, 2 * PG_MM_RB, occ2, canSplit, &main2) : 1e30;
+    bool two = shortList && t2 < t1;
+    if (const char *e = getenv("PG_MM_R")) two = shortList && atoi(e) == 2;
     const int rbm = two ? 2 * PG_MM_RB : PG_MM_RB, occm = two ? occ2 : occ1;
     const int modeM = two ? PG_MODE_KNN_SHORT2 : (shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN);
-    long long mainRows = nrows;
-    if (shortList && workspace && p.knnGuess > 0 && ncols >= 65536 && nrows > PG_SPLIT_MIN_ROWS && !getenv("PG_ROWS_PER_WAVE") &&
-        !(getenv("PG_MM_SPLIT") && atoi(getenv("PG_MM_SPLIT")) == 0)) {
-      const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4;
-      const long long passes = (nrows + rbm - 1) / rbm, slots = simds * occm;
-      long long held = 0;
-      if (passes <= slots) {                                // one round: one wave fewer per SIMD
-        const long long w = (passes + simds - 1) / simds;
-        if (w >= 3) held = (w - 1) * simds * rbm;
-      } else {                                              // several: whole rounds of full occupancy
-        held = nrows / (slots * rbm) * (slots * rbm);
-      }
-      if (held > 0 && nrows - held <= 128ll * rbm) mainRows = held;
-    }
+    const long long mainRows = two ? main2 : main1;
     plan_mm(mainRows, &p, &grid, rbm, occm, true);
     p.nrows = mainRows;
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from prograph_amd import _native as nat, synth
 N = int(os.environ.get("TR_N", "200000"))
-p = nat.pack(torch.from_numpy(synth.clustered_tokens(N, 64)), bits=5)
+L = int(os.environ.get("TR_L", "64"))
+p = nat.pack(torch.from_numpy(synth.clustered_tokens(N, L)), bits=5)
 out = (torch.empty((N, 16), dtype=torch.int32, device=p.buf.device), torch.empty((N, 16), dtype=torch.uint8, device=p.buf.device))
 for _ in range(4):
     nat.knn_graph(p, p, 16, out=out)
