@@ -296,7 +296,7 @@ def run_workload(name, G, rank, dev, use_dist, backend, steps, warmup, want_pcie
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in kern_ev]))
     ms_per_step = elapsed / steps * 1e3
     value = float(rows_local) * N * G * steps / elapsed         # every rank does rows_local x N
-    thr_default = "20000" if wl["mode"] == "knn" else ("60000" if L <= 32 else "40000")     # pg_api.hip: use_mm_engine
+    thr_default = "20000" if wl["mode"] == "knn" else ("36000" if L <= 32 else "28000")     # pg_api.hip: use_mm_engine
     engine = "mfma" if rows_local >= int(os.environ.get("PG_ENGINE_MIN_ROWS", thr_default)) else "valu"
     engine = os.environ.get("PG_ENGINE", engine)
     if wl["mode"] == "lev":

@@ -145,9 +145,11 @@ int pg_hamming_dense(const void *x_planes, int64_t n, int64_t x_npad,
  * Replaces the hot loop `distance(X,batch)` -> `comp(d,eps) & (d>0)` -> `torch.where`
  * -> gather of `build_graph` (prograph/prograph.py:731-739; K2..K7) for rows
  * [row0, row0+nrows) of `row_planes` against all `ncols` sequences of `col_planes`.
- * For every row the matching column indices are written in ascending order into the
- * row's slot (capacity `cap`), and the exact number of matches into counts[] even when
- * it exceeds `cap` (pg_eps_compact recomputes such rows).
+ * For every row the matching column indices are written into the row's slot (capacity `cap`)
+ * in ascending order of their 32-column tile - within one tile in any order: a slot is an
+ * intermediate, pg_eps_compact puts every entry in its place (an entry is at most 31 positions
+ * from it) - and the exact number of matches into counts[] even when it exceeds `cap`
+ * (pg_eps_compact recomputes such rows).
  *   cmp, eps   PG_CMP_* and the threshold; pairs with d == 0 are always excluded
  *   slot_idx   int32 [nrows*cap], slot_w uint8 [nrows*cap], counts uint32 [nrows]
  */

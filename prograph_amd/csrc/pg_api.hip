@@ -678,10 +678,11 @@ static bool use_mm_engine(int64_t nrows, int l = 64, bool knn = true) {
     if (!strcmp(e, "mfma")) return true;
     if (!strcmp(e, "valu")) return false;
   }
-  // eps crosses at ~40k rows (tools/engine_crossover.py), eps graphs of sequences of one group (L <= 32: only 32
-  // signature bits) at ~60k (N = 50k L = 32: VALU engine 0.68 ms, MFMA engine 0.80); kNN, since the MFMA engine queues
-  // its candidates lane-parallel, at ~20k (profiles/r03_engine_landscape.txt: N = 20k 0.30 vs 0.32 ms, 50k 0.59 vs 1.19)
-  const long long dflt = knn ? 20000 : (l <= 32 ? 60000 : 40000);
+  // Since the MFMA engine queues its candidates lane-parallel (kNN, and eps slots too: pg_mm.h push_signs) it wins from
+  // ~20k rows for kNN (profiles/r03_engine_crossover.txt: N = 16k L = 64 0.24 vs 0.29 ms, L = 32 0.24 vs 0.20) and from
+  // ~28k for eps (N = 24k: 0.34 vs 0.27; 32k: 0.41 vs 0.53), ~36k for sequences of one group (L <= 32: only 32 signature
+  // bits; N = 50k L = 32 symmetric: 0.43 vs 0.53).  Round 2: 40k / 60k.
+  const long long dflt = knn ? 20000 : (l <= 32 ? 36000 : 28000);
   const long long thr = getenv("PG_ENGINE_MIN_ROWS") ? atoll(getenv("PG_ENGINE_MIN_ROWS")) : dflt;
   return nrows >= thr;
 }
@@ -800,6 +801,7 @@ int pg_eps_slots(const void *row_planes, int64_t row_npad, int64_t row0, int64_t
   p.hi1 = (p.lo > 0xFFFFFF00u - 1u) ? 0u : p.lo + p.span + 1u;   // empty interval: nothing can match
   p.cap = (u32)cap; p.slotIdx = slot_idx; p.slotW = slot_w; p.counts = counts;
   int grid = 0;
+  p.epsOrdered = getenv("PG_EPS_ORDERED") && atoi(getenv("PG_EPS_ORDERED")) != 0;
   if (use_mm_engine(nrows, l, false)) {
     plan_mm(nrows, &p, &grid);
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
@@ -843,6 +845,7 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
   // dispatched in row order, i.e. longest first, which balances by itself once there are a few
   // waves per resident slot.  Measured (tools/eps_sym_probe.py): 8 rows per wave at N = 50k, 16 at
   // N = 100k .. 200k (more rows: too few waves to balance; fewer: the per-wave column stream shows).
+  p.epsOrdered = getenv("PG_EPS_ORDERED") && atoi(getenv("PG_EPS_ORDERED")) != 0;
   if (use_mm_engine(n, l, false)) {
     plan_mm(n, &p, &grid);
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;

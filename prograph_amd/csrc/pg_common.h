@@ -318,6 +318,7 @@ struct NsqParams {
   unsigned char *slotW;
   u32 *counts;
   u32 *countsLo;  // EPS_SYM: per row, matches found from the other side (column < row), filled with atomics
+  int epsOrdered; // pg_mm.h eps: 1 = a row's matches reach its slot in ascending column order (PG_EPS_ORDERED=1, A/B runs); 0: by tile
   int *slotAux;   // EPS_SYM, optional: for a front entry the back position of its mirror entry in the other row's slot
   // knn: lanes [knnFirst, knnFirst + k) of the sorted 64-key list are written; keys <= floorKeys[row]
   // are ignored (continuation rounds for k > 63); lastKeys[row] receives the last written key

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   const u32 bias = kEps ? opaque_vgpr(0u - p.lo) : 0u;     // eps: -lo rides in the popcount accumulator
   // eps entries carry the row in 5 bits above a 27-bit column; wider problems run the direct form
   const bool canFilterK = p.filter != 0 && (!kEps || p.ncols < (1ll << 27));   // (per pass: canFilter below)
+  const bool epsOrdered = kEps && (p.fillIndptr != nullptr || p.epsOrdered != 0);   // (see push_signs)
   constexpr int SH = kEps ? 27 : 24;
   // arguments that only cold code needs (staging a pass, storing results, the dense forms) are read from the
   // kernel-argument segment where they are used: held in SGPRs across the sweep they crowd the loop state of
@@ -558,6 +559,10 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       for (int r = 15; r >= 0; --r) a = __builtin_amdgcn_alignbit(a, (u32)d[r], 31);   // (a << 1) | sign
       return a;
     };
+    // eps slots (pg_eps_slots[_sym]) take the lane-parallel form as well: a row's matches then reach its slot in ascending
+    // order of their 32-column TILE but in any order within one - pg_compact_kernel puts every entry in its place by a
+    // rank among its 31 neighbours on either side.  The fill pass (pg_eps_fill_rows: straight into the CSR, nothing
+    // behind it that could sort) keeps the ordered form below: `epsOrdered`.
     // kNN (the order of a row's candidates does not matter to its list): LANE PARALLEL queueing - per turn every
     // lane that has any candidate queues its lowest one.  The cluster mates of 32 consecutive rows sit on a tile's
     // diagonal - 32 different lanes - so a tile takes one or two turns: 16 (sign words) + ~12 per turn vector
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         tm &= tm - 1u;
         u32 a = t == 1 ? am1 : (t == 2 ? am2 : (t == 3 ? am3 : am0));
         const u32 ebase = ((u32)(4 * (lane >> 5)) << SH) | (u32)((S * 4 + t) * 32 + (lane & 31));
-        if constexpr (MODE == PG_MODE_KNN) {
+        if (MODE == PG_MODE_KNN || !epsOrdered) {
           u64 mb = __builtin_amdgcn_ballot_w64(a != 0u);
           while (mb) {
             // bit b: row block b >> 4, register b & 15; the register's row in its block: (r & 3) + 8 * (r >> 2) = r + (r & 12)

@@ -714,9 +714,35 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_compact_kernel(const Compact
         p.weights[dst + rank] = p.e.slotW[src + p.e.cap - 1u - i];
       }
     }
-    for (u32 i = lane; i < up; i += 64) {
-      p.indices[dst + lo + i] = p.e.slotIdx[src + i];
-      p.weights[dst + lo + i] = p.e.slotW[src + i];
+    // The front part is in ascending order of the columns' 32-column TILE, within a tile in any order (the MFMA engine
+    // queues a tile's candidates lane-parallel, pg_mm.h push_signs; the VALU engine and the dense forms write in order):
+    // entries 32 or more positions apart are in order already, so an entry's place is 31 fewer than its position at
+    // most, plus the entries with a smaller column among its 31 neighbours on either side.
+    if (up <= (u32)PG_SORT_MAX) {
+      u32 *lc = &lcol[threadIdx.x >> 6][0];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                      // (the back part above is done with the buffer)
+      for (u32 i = lane; i < up; i += 64) lc[i] = (u32)p.e.slotIdx[src + i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (u32 i = lane; i < up; i += 64) {
+        const u32 ecol = lc[i];
+        const u32 j0 = i > 31u ? i - 31u : 0u, j1 = i + 32u < up ? i + 32u : up;
+        u32 rank = j0;
+        for (u32 j = j0; j < j1; ++j) rank += lc[j] < ecol ? 1u : 0u;
+        p.indices[dst + lo + rank] = (int)ecol;
+        p.weights[dst + lo + rank] = p.e.slotW[src + i];
+      }
+    } else {
+      for (u32 i = lane; i < up; i += 64) {
+        const u32 ecol = (u32)p.e.slotIdx[src + i];
+        const u32 j0 = i > 31u ? i - 31u : 0u, j1 = i + 32u < up ? i + 32u : up;
+        u32 rank = j0;
+        for (u32 j = j0; j < j1; ++j) rank += (u32)p.e.slotIdx[src + j] < ecol ? 1u : 0u;
+        p.indices[dst + lo + rank] = (int)ecol;
+        p.weights[dst + lo + rank] = p.e.slotW[src + i];
+      }
     }
     return;
   }
