@@ -725,7 +725,7 @@ static int mm_occupancy(int groups, int mode, int bits) {
 // passes; 1.26 / 1.52 / 1.87 for two / three / four waves of 64-row passes, the same for 48..64 rows).  So: the fewest
 // waves per SIMD that hold the rows, the rows spread evenly over exactly that many waves on every SIMD.  (Round 2 spread
 // the rows over ~97 % of ALL slots: 65 536 rows took 1.11 ms as 4096 passes of 16 rows, 0.79 as 2048 of 32.)
-static void plan_mm(int64_t nrows, NsqParams *p, int *grid, int rb = PG_MM_RB, int occ = 4, bool knn = false) {   // rb: rows per pass of the instance (32 or 64)
+static void plan_mm(int64_t nrows, NsqParams *p, int *grid, int rb = PG_MM_RB, int occ = 4, bool knn = false, int uniformRows = 0) {   // rb: rows per pass of the instance (32 or 64)
   long long rpw = rb, tailFrom = (nrows + rb - 1) / rb, tailRows = rb;
   const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4;
   const long long slots = simds * (occ < 1 ? 1 : occ);
@@ -733,9 +733,11 @@ static void plan_mm(int64_t nrows, NsqParams *p, int *grid, int rb = PG_MM_RB, i
   const char *t = getenv("PG_MM_TAIL");
   // eps launches keep round 2's spreading rule: their passes are not equal work (symmetric: a pass sweeps the columns
   // above its rows only; matches cost per row) - tools/dbg/plan_ab.py: N = 50k eps <= 2 symmetric 0.58 ms against 0.79
-  const bool oldPlan = !knn || (getenv("PG_MM_PLAN") && atoi(getenv("PG_MM_PLAN")) == 2);   // (A/B: PG_MM_PLAN=2)
-  if (e && atoi(e) > 0) {
-    rpw = atoi(e) < rb ? atoi(e) : rb;                      // (a wave sweeps one pass of at most rb rows at a time)
+  const int planEnv = getenv("PG_MM_PLAN") ? atoi(getenv("PG_MM_PLAN")) : 0;               // (A/B: 2 = round 2's rule, 1 = the new one for eps too)
+  const bool oldPlan = planEnv == 2 || (!knn && planEnv != 1);
+  if ((e && atoi(e) > 0) || uniformRows > 0) {
+    const int want = e && atoi(e) > 0 ? atoi(e) : uniformRows;
+    rpw = want < rb ? want : rb;                            // (a wave sweeps one pass of at most rb rows at a time)
     tailFrom = (nrows + rpw - 1) / rpw; tailRows = rpw;
   } else if (!oldPlan) {
     if (tailFrom <= slots) {
@@ -847,7 +849,15 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
   // N = 100k .. 200k (more rows: too few waves to balance; fewer: the per-wave column stream shows).
   p.epsOrdered = getenv("PG_EPS_ORDERED") && atoi(getenv("PG_EPS_ORDERED")) != 0;
   if (use_mm_engine(n, l, false)) {
-    plan_mm(n, &p, &grid);
+    // the symmetric sweep's passes are not equal work (a pass sweeps the columns above its rows): about one and a half
+    // rounds of passes balance best (tools/dbg/eps_plan.py: N = 50k 8 rows per pass 0.40 ms against 0.43 / 0.59 for 14 / 32;
+    // N = 100k 16 rows 0.61 against 0.66 / 0.71 for 26 / 32; N = 200k 32 rows 1.12 against 1.62 for 16)
+    long long rs = (n + 6143) / 6144;
+    rs = (rs + 1) / 2 * 2;
+    rs = rs < 8 ? 8 : (rs > PG_MM_RB ? PG_MM_RB : rs);
+    // (records of up to three chunks - four waves per SIMD; longer ones, N = 100k L = 128: 0.75 against 0.67 with the old rule)
+    const bool fine = pg_nchunks(l, bits) <= 3 && !(getenv("PG_MM_PLAN") && atoi(getenv("PG_MM_PLAN")) == 2);
+    plan_mm(n, &p, &grid, PG_MM_RB, 4, false, fine ? (int)rs : 0);
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
     return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS_SYM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps sym)");
   }
