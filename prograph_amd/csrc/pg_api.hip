@@ -949,15 +949,22 @@ int pg_eps_fill_rows(const void *row_planes, int64_t row_npad, int64_t row0, con
   return launched(kMm[pg_ngroups(l) - 1](PG_MODE_EPS, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(eps fill)");
 }
 
-// What a kNN launch of `nrows` rows takes on the 32-row (rb = 32) or the 64-row (rb = 64) short-list instance, in units of
-// "ms per 200 000 columns", from the measured cost of a round of waves (profiles/r03_pass_plan.txt: it follows the waves per
-// SIMD, not the rows per wave), and which rows go into plain passes (*mainRows; the rest: column pieces, knn_launch).
-//   one round   : T(w), w = waves on the busiest SIMD; with w >= 3 and at most 128 row blocks beyond w - 1 full waves:
-//                 T(w - 1) + the pieces
+// What a kNN launch of `nrows` rows x `ncols` columns takes (ms) on the 32-row (rb = 32) or the 64-row (rb = 64) short-list
+// instance, and which rows go into plain passes (*mainRows; the rest: column pieces, knn_launch).  A round of waves costs
+//     T(w, ncols) = S[w] + H[w] * ncols / 100 000,     w = waves on the busiest SIMD
+// (it follows the waves per SIMD, not the rows per wave: profiles/r03_pass_plan.txt).  S is what does not grow with the
+// columns - the candidates of a row's cluster mates, pass set-up, the tail - H the sweep itself; calibrated at 300 000
+// and 900 000 columns of cfg3-like data (tools/dbg/calib.py).  The 64-row instance sweeps twice the rows per fragment
+// (H per row 0.6 x) but pays more per pass: 131 072 rows x 200 000 columns 1.07 ms (32-row passes) against 1.27, x
+// 1 000 000 columns 4.9 against 3.6 (BASELINE configs[3]: one GPU's 125 000 x 1M block 5.5 -> 3.6 ms).
+//   one round   : T(w); with w >= 3 and at most 128 row blocks beyond w - 1 full waves: T(w - 1) + the pieces
 //   more rounds : whole rounds of full occupancy + (a last round: T(its waves) | at most 128 row blocks: the pieces)
-static double knn_plan_cost(long long nrows, int rb, int occ, bool canSplit, long long *mainRows) {
-  static const double T1[4] = {0.70, 0.79, 0.94, 1.12}, T2[4] = {0.95, 1.22, 1.45, 1.75};
-  const double *T = rb > PG_MM_RB ? T2 : T1, kPieces = 0.08;
+static double knn_plan_cost(long long nrows, long long ncols, int rb, int occ, bool canSplit, long long *mainRows) {
+  static const double S1[4] = {0.43, 0.42, 0.37, 0.12}, H1[4] = {0.148, 0.200, 0.294, 0.477};
+  static const double S2[4] = {0.64, 0.69, 0.64, 0.54}, H2[4] = {0.229, 0.292, 0.404, 0.557};
+  const bool big = rb > PG_MM_RB;
+  const double c = (double)ncols / 1e5, kPieces = 0.04 * c;
+  auto T = [&](long long w) { return (big ? S2 : S1)[w - 1] + (big ? H2 : H1)[w - 1] * c; };
   const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4;
   occ = occ < 1 ? 1 : (occ > 4 ? 4 : occ);
   const long long passes = (nrows + rb - 1) / rb, slots = simds * occ, maxRem = 128ll * rb;
@@ -966,18 +973,18 @@ static double knn_plan_cost(long long nrows, int rb, int occ, bool canSplit, lon
     const long long w = (passes + simds - 1) / simds;
     if (canSplit && w >= 3 && nrows - (w - 1) * simds * rb <= maxRem) {
       *mainRows = (w - 1) * simds * rb;
-      return T[w - 2] + kPieces;
+      return T(w - 1) + kPieces;
     }
-    return T[w - 1];
+    return T(w);
   }
   const long long full = nrows / (slots * rb), rem = nrows - full * slots * rb;
-  double t = (double)full * T[occ - 1];
+  double t = (double)full * T(occ);
   if (rem > 0) {
     if (canSplit && rem <= maxRem) {
       *mainRows = full * slots * rb;
       t += kPieces;
     } else {
-      t += T[((rem + rb - 1) / rb + simds - 1) / simds - 1];
+      t += T(((rem + rb - 1) / rb + simds - 1) / simds);
     }
   }
   return t;
@@ -1038,8 +1045,8 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     const bool canSplit = shortList && workspace && p.knnGuess > 0 && ncols >= 65536 && nrows > PG_SPLIT_MIN_ROWS &&
                           !getenv("PG_ROWS_PER_WAVE") && !(getenv("PG_MM_SPLIT") && atoi(getenv("PG_MM_SPLIT")) == 0);
     long long main1 = nrows, main2 = nrows;
-    const double t1 = knn_plan_cost(nrows, PG_MM_RB, occ1, canSplit, &main1);
-    const double t2 = shortList ? knn_plan_cost(nrows, 2 * PG_MM_RB, occ2, canSplit, &main2) : 1e30;
+    const double t1 = knn_plan_cost(nrows, ncols, PG_MM_RB, occ1, canSplit, &main1);
+    const double t2 = shortList ? knn_plan_cost(nrows, ncols, 2 * PG_MM_RB, occ2, canSplit, &main2) : 1e30;
     bool two = shortList && t2 < t1;
     if (const char *e = getenv("PG_MM_R")) two = shortList && atoi(e) == 2;
     const int rbm = two ? 2 * PG_MM_RB : PG_MM_RB, occm = two ? occ2 : occ1;
