@@ -414,7 +414,7 @@ def test_rows_beyond_a_full_round_in_column_pieces(nat, case, monkeypatch):
 def test_full_windows_on_dense_data_and_on_the_sharded_slice(nat):
     """Whole 4 096-row windows against the oracle where a full matrix is out of reach on the host: (i) cfg3's shape on
     DENSE data (one cluster: the folded / exact forms of the engine), (ii) rank 3's block of BASELINE.json configs[3]
-    (125 000 rows x 1 000 000 columns), (iii) a 400 000-row launch of the same problem, the window straddling the
+    (125 000 rows x 1 000 000 columns: every kNN entry of the block, an eps window), (iii) a 400 000-row launch of the same problem, the window straddling the
     4 096th pass, i.e. reaching into the passes the persistent waves fetch through the counter."""
     from oracle import c_oracle as C
     from prograph_amd import synth, sharded
@@ -434,9 +434,10 @@ def test_full_windows_on_dense_data_and_on_the_sharded_slice(nat):
     kidx, kd = nat.knn_graph(p, p, k, row0=lo, nrows=hi - lo)
     indptr, idx, w = nat.eps_graph(p, p, nat.CMP_LE, 2, row0=lo, nrows=hi - lo, cap=64)
     torch.cuda.synchronize()
-    w0 = 60_000                                               # rows of the block (3 907 passes: one round of the grid)
-    ridx, rd = C.knn(tok, k, row0=lo + w0, nrows=4096, fast=True)
-    assert np.array_equal(kidx[w0:w0 + 4096].cpu().numpy(), ridx) and np.array_equal(kd[w0:w0 + 4096].cpu().numpy(), rd)
+    # kNN: the WHOLE block (1.25e11 pairs: half a minute of the vectorised oracle) - 64-row passes, two waves per SIMD
+    ridx, rd = C.knn(tok, k, row0=lo, nrows=hi - lo, fast=True)
+    assert np.array_equal(kidx.cpu().numpy(), ridx) and np.array_equal(kd.cpu().numpy(), rd)
+    w0 = 60_000                                               # eps: a window of the block
     rp, ri, rw = C.eps_csr(tok, 0, 2, row0=lo + w0, nrows=4096, fast=True)
     ip = indptr.cpu().numpy()
     assert np.array_equal(ip[w0:w0 + 4097] - ip[w0], rp)
