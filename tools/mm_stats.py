@@ -1,6 +1,6 @@
 """Event counters of the MFMA engine (debug build of the library with -DPG_MM_STATS:
    make -C prograph_amd/csrc BUILD=build_stats OUT=../libprograph_hip_stats.so EXTRA=-DPG_MM_STATS).
-   usage: mm_stats.py [case ...]   cases: cfg3 random dense c64 cfg2"""
+   usage: mm_stats.py [case ...]   cases: cfg3 random dense c64 cfg2 cfg3sorted cfg3shuffled"""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,7 +28,10 @@ def timed(f):
 rng = np.random.RandomState(1)
 CASES = {"cfg3": lambda: synth.clustered_tokens(200000, 64), "random": lambda: rng.randint(1, 21, size=(200000, 64)).astype(np.uint8),
          "dense": lambda: synth.clustered_tokens(200000, 64, members=200000), "c64": lambda: synth.clustered_tokens(200000, 64, members=64),
-         "cfg2": lambda: synth.clustered_tokens(50000, 32), "dense50k": lambda: synth.clustered_tokens(50000, 64, members=50000)}
+         "cfg2": lambda: synth.clustered_tokens(50000, 32), "dense50k": lambda: synth.clustered_tokens(50000, 64, members=50000),
+         # cfg3's sequences in another order: cluster mates adjacent / scattered without the generator's regular stride
+         "cfg3sorted": lambda: (lambda t: np.ascontiguousarray(t[np.lexsort(t.T[::-1])]))(synth.clustered_tokens(200000, 64)),
+         "cfg3shuffled": lambda: (lambda t: np.ascontiguousarray(t[np.random.RandomState(3).permutation(len(t))]))(synth.clustered_tokens(200000, 64))}
 for name in (sys.argv[1:] or ["cfg3", "dense", "random"]):
     tok = CASES[name]()
     N = tok.shape[0]
