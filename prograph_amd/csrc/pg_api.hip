@@ -1008,7 +1008,6 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
   p.knnGuess = getenv("PG_KNN_GUESS") ? (u32)atoi(getenv("PG_KNN_GUESS")) : (mm ? guessMm : guessValu);
   if (p.filter == 0) p.knnGuess = 0;                       // no stage 1, nothing to cap
   p.knnIdx = idx_out; p.knnDist = dist_out;
-  p.mmRotate = !(getenv("PG_MM_ROTATE") && atoi(getenv("PG_MM_ROTATE")) == 0);
   int grid = 0;
   auto launch_valu = [&](NsqParams &q) -> int {
     int g = 0;

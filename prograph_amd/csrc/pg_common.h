@@ -299,7 +299,6 @@ struct NsqParams {
   // below the cap, so a merged list whose (k+1)-th distance ends below the cap is exact; the merge flags the row
   // blocks where a row's does not (mmBlockFlags[block] = 1), and a third launch - the plain kernel over the same
   // rows, passes whose flag is 0 skipped - sweeps those blocks again in full.
-  int mmRotate;                     // kNN: a pass's sweep starts at the super-tile of its own rows (PG_MM_ROTATE=0: at column 0)
   int mmPieces;
   long long mmPieceFrom;            // passes from this index on are column pieces (the ones before: plain passes of rowsPerWave rows)
   u32 *mmPartial;                   // ... of the rows from mmPieceFrom * rowsPerWave on

@@ -56,9 +56,6 @@ typedef int pg_v16i __attribute__((ext_vector_type(16)));
 #define PG_MM_GROUP_ROWS 4    // folded form: rows per group of straight-line code (their folds: 20 SGPRs in flight)
 #define PG_MM_DIRECT_RUN 8   // super-tiles of dense form before the MFMA filter is probed again
 #define PG_MM_PRIO_STEPS 16  // R = 2: steps of the progress-driven issue priority along a sweep
-#ifndef PG_MM_ROT_BACK
-#define PG_MM_ROT_BACK 8     // kNN: the rotated sweep starts this many super-tiles (x 128 columns) before the pass's own rows
-#endif
 #ifndef PG_EXP_SAMETILE
 #define PG_EXP_SAMETILE 0   // experiment builds: 1 = every fragment load reads the same super-tile (L1 hits; wrong results)
 #endif
@@ -246,9 +243,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     const u32 G0 = (MODE == PG_MODE_KNN && canFilter) ? p.knnGuess : 0u;
     u64 failed = 0;                                         // kNN: rows that lost their optimistic cap (bit = row)
     u32 resweep = 0;                                        // kNN: 1 in phase 1 (early super-tiles again for the failed rows)
-    u32 loose = 0;                                          // kNN: 1 where a column may win a TIE against a list entry, i.e. where columns are met
-                                                            // that are smaller than ones met before: phase 1, and the wrapped part of a rotated sweep
-    int sredo = 0;                                          // kNN: the first sredo super-tiles of the sweep (logical positions) are swept again for them
+    int sredo = 0;                                          // kNN: super-tiles [0, sredo) are swept again for them
     // list geometry: lanes / entries [lfirst, lfirst + k) are written out, entry thrLane is the row's threshold
     const int thrLane = kPar ? KL - 1 : p.knnFirst + p.k - 1;   // last list entry that is still needed
     const int lfirst = kPar ? KL - p.k : p.knnFirst;            // (kPar: the host guarantees knnFirst == 1, k + 1 <= KL)
@@ -327,14 +322,14 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
 
     auto publish = [&](int row, u32 thr) {                  // kNN: a row's threshold moved
       const u32 cp = __builtin_amdgcn_readlane(capv, row);
-      const u32 b = (thr >> 24) + loose;                    // (lb <= distance bound may still win a tie)
+      const u32 b = (thr >> 24) + resweep;                  // phase 1: lb <= distance bound may still win a tie
       set_bound(row, b < cp ? b : cp);
     };
     // kNN: the bounds of ALL rows from the row-indexed state (after a flush that moved several thresholds at once):
     // min(threshold distance [+1 in phase 1], cap); 0 for rows past nr and, in phase 1, for the frozen rows
     auto republish_all = [&]() {
       const bool live = lane < nr && (!resweep || ((failed >> lane) & 1ull));
-      const u32 b = (thrv >> 24) + loose;                   // open lists read 255
+      const u32 b = (thrv >> 24) + resweep;                 // open lists read 255
       set_all_bounds(live ? (b < capv ? b : capv) : 0u);
     };
     // EPS_SYM: a match (row, col), col > row, also belongs to row `col` (owned by another wave): its
@@ -797,7 +792,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
       if constexpr (kEps) return lane < nr ? 0u - p.hi1 : 0u;
       const u32 t = thrv >> 24;                             // open lists read 255
       const bool live = lane < nr && (!resweep || ((failed >> lane) & 1ull));
-      return live ? 0u - ((t < capv ? t : capv) + loose) : 0u;
+      return live ? 0u - ((t < capv ? t : capv) + resweep) : 0u;
     };
     auto load_rec = [&](uint4 (&dst)[Q], long long col) {
 #pragma unroll
@@ -949,36 +944,12 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // drain: one copy of flush).  No checkpoints without a cap and in phase 1.
     constexpr int kNoCk = 0x7FFFFFFF;
     // (a column piece keeps the cap to its end: what the cap hides from it, the merge detects - NsqParams::mmPieces)
-    // The sweep of a kNN pass is ROTATED: it starts at the super-tile that holds the pass's own rows (a self graph: column
-    // index = row index) and wraps around - lists do not care about the order of the columns.  Where similar sequences
-    // sit together (a file sorted by family, by name, lexicographically) a row then meets its neighbours in the first
-    // super-tiles and sweeps the rest under a tight bound; started at column 0 its list stayed empty until the sweep
-    // reached its own neighbourhood, the 1/32 checkpoint took it for an unclustered row and lifted its cap: every pair a
-    // candidate (cfg3's sequences in lexicographic order: 17.5 ms; generator order, mates 781 columns apart: 1.6 either way).
-    // Logical position l = 0 .. len-1 <-> super-tile: segment 0 = [s0, se) (l < lenA), segment 1 = [sb, s0).  Checkpoints,
-    // the second phase's range and the priority steps are logical positions; `pbase` + l = the super-tile within a segment.
-    int s0 = kSym ? (int)(pr0 / PG_MM_ST) : sb;            // EPS_SYM: from the super-tile that holds the pass's first row, no wrap
-    if constexpr (MODE == PG_MODE_KNN) {
-      if (npieces == 1 && p.mmRotate) {
-        // (PG_MM_ROT_BACK super-tiles before the rows' own: in sorted data a row's neighbours sit on BOTH sides of it; the ones
-        //  before it would otherwise be met last, and a row at the end of its family would look unclustered at the checkpoints)
-        const long long own = (K().row0 + pr0) / PG_MM_ST - PG_MM_ROT_BACK;
-        if (own > sb && own < se) s0 = (int)own & ~1;       // (even: the folded form's tiles are pairs of super-tiles)
-      }
-    }
-    const int lenA = se - s0;
-    const int len = (MODE == PG_MODE_KNN) ? se - sb : lenA;
-    int pbase = s0, lcap = lenA;                            // of the segment at work
-    int lck = (MODE == PG_MODE_KNN && G0 && npieces == 1) ? ((len + 31) >> 5) : kNoCk;   // the next checkpoint, logical
-    int nextCk = kNoCk;                                     // ... as a super-tile of the segment at work (kNoCk: not in it)
-    auto place_ck = [&]() { nextCk = (lck != kNoCk && lck <= lcap) ? pbase + lck : kNoCk; };
+    int nextCk = (MODE == PG_MODE_KNN && G0 && npieces == 1) ? ((nst + 31) >> 5) : kNoCk;
     auto checkpoint = [&](int snext) {                      // the sweep has reached super-tile snext >= nextCk; queue empty
       if constexpr (MODE == PG_MODE_KNN) {
-        const int lpos = snext - pbase;
-        const int sw2 = (len + 7) >> 3;
-        const bool at2 = lpos >= sw2;
-        lck = at2 ? kNoCk : sw2;
-        place_ck();
+        const int sw2 = (nst + 7) >> 3;
+        const bool at2 = snext >= sw2;
+        nextCk = at2 ? kNoCk : sw2;
         const bool mine = lane < nr && !((failed >> lane) & 1ull);
         u32 dref = thrv >> 24;                             // open lists read 255
         if (!at2) dref = mine ? lstbuf[wv][lane < RB ? lane : 0][lfirst] >> 24 : 0u;
@@ -986,7 +957,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         const u64 now = __builtin_amdgcn_ballot_w64(late);
         if (now) {
           failed |= now;
-          sredo = lpos;
+          sredo = snext;
           if (late) capv = 255u;
           const u32 b = thrv >> 24;
           set_all_bounds(lane < nr ? (b < capv ? b : capv) : 0u);
@@ -1058,84 +1029,68 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     };
 
     PG_T1(21, tp0);
+    int send = se;
     int drun = 0;                                           // super-tiles per dense run (0: the first of a series)
-    int lend = len;                                         // logical end of the phase at work
+    const int sbeg = kSym ? (int)(pr0 / PG_MM_ST) : sb;    // EPS_SYM: from the super-tile that holds the pass's first row
     for (;;) {
-      for (int seg = 0; seg < 2; ++seg) {
-        const int l0 = seg ? lenA : 0, l1 = seg ? len : lenA;
-        lcap = l1 < lend ? l1 : lend;
-        if (l0 >= lcap) continue;
-        pbase = seg ? sb - lenA : s0;
-        if constexpr (MODE == PG_MODE_KNN) {
-          // the wrapped part meets columns below the ones already seen: an equal distance may now win its tie
-          const u32 want = (resweep || seg) ? 1u : 0u;
-          if (want != loose) {
-            loose = want;
-            republish_all();
-          }
+      int S = sbeg;
+      int dEnd = canFilter ? 0 : send;                      // a dense run is in progress up to here (no filter: throughout)
+      for (;;) {
+        if (S >= send || S >= nextCk) {                     // end of the sweep / a checkpoint: the queue is drained HERE
+          while (qn > 0) flush();
+          if (S >= nextCk) checkpoint(S);
+          if (S >= send) break;
         }
-        int S = pbase + l0;
-        const int send = pbase + lcap;
-        place_ck();
-        int dEnd = canFilter ? S : send;                    // a dense run is in progress up to here (no filter: throughout)
-        for (;;) {
-          if (S >= send || S >= nextCk) {                   // end of the segment / a checkpoint: the queue is drained HERE
-            while (qn > 0) flush();
-            if (S >= nextCk) checkpoint(S);
-            if (S >= send) break;
-          }
-          if (S < dEnd) {
-            S = run_dense(S, dEnd);                         // (returns early where a checkpoint is due)
-            continue;
-          }
-          if (stale) { PG_ST(19, 1); refresh_bias(); }
-          // Issue priority falls with a wave's progress (16 steps along the sweep, the priority cycling 3..0 within four of
-          // them): the waves of a SIMD advance together.  Left alone the arbiter favours the oldest wave, the three waves of
-          // a SIMD finish at 0.70 / 0.83 / 1.0 of the launch (profiles/r03_pass_timeline.txt) and its last third runs with
-          // two, then one wave per SIMD.  cfg3 1.74 -> 1.65 ms, N = 270k 2.62 -> 2.42 (4 steps: 1.69; 64: 1.69); the 32-row
-          // instances do not gain (N = 100k L = 128: 0.98 -> 0.99; N = 50k: 0.50 -> 0.52), nor do eps launches (3.02 / 3.00 ms): left alone.
-          if constexpr (R == 2) {
-            const int step = ((S - pbase) * PG_MM_PRIO_STEPS) / (len > 0 ? len : 1);
-            const int pr = step & 3;
-            if (pr == 0) __builtin_amdgcn_s_setprio(3);
-            else if (pr == 1) __builtin_amdgcn_s_setprio(2);
-            else if (pr == 2) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-          }
-          const int Sin = S;
-          PG_ST(18, 1);
-          PG_T0(ts0);
-          const int rc = scan(S, send < nextCk ? send : nextCk, send - 1);
-          PG_T1(16, ts0);
-          PG_ST(0, S - Sin + (rc ? 1 : 0));                 // (counted here: nothing but the loop's own state lives in scan())
-          PG_ST(9, resweep ? S - Sin + (rc ? 1 : 0) : 0);
-          if (S != Sin) drun = 0;                           // a clean stretch ends a series of dense runs
-          if (rc == 0) continue;
-          if (rc == 1) {                                    // candidates queued, the MFMA form goes on
-            PG_T0(tq0);
-            push_signs(S);
-            PG_T1(17, tq0);
-            ++S;
-            drun = 0;
-            continue;
-          }
-          // the signature is not selective here: a run of the dense form
-          const int drun0 = K().mmDirectRun;
-          if (!drun) drun = drun0;
-          dEnd = S + drun < send ? S + drun : send;
-          drun = drun * 2 < 8 * drun0 ? drun * 2 : 8 * drun0;  // back off while every probe is dense
-          PG_ST(3, 1);
-          PG_ST(4, dEnd - S);
+        if (S < dEnd) {
+          S = run_dense(S, dEnd);                           // (returns early where a checkpoint is due)
+          continue;
         }
+        if (stale) { PG_ST(19, 1); refresh_bias(); }
+        // Issue priority falls with a wave's progress (16 steps along the sweep, the priority cycling 3..0 within four of
+        // them): the waves of a SIMD advance together.  Left alone the arbiter favours the oldest wave, the three waves of
+        // a SIMD finish at 0.70 / 0.83 / 1.0 of the launch (profiles/r03_pass_timeline.txt) and its last third runs with
+        // two, then one wave per SIMD.  cfg3 1.74 -> 1.65 ms, N = 270k 2.62 -> 2.42 (4 steps: 1.69; 64: 1.69); the 32-row
+        // instances do not gain (N = 100k L = 128: 0.98 -> 0.99; N = 50k: 0.50 -> 0.52), nor do eps launches (3.02 / 3.00 ms): left alone.
+        if constexpr (R == 2) {
+          const int step = ((S - sb) * PG_MM_PRIO_STEPS) / (se - sb > 0 ? se - sb : 1);
+          const int pr = step & 3;
+          if (pr == 0) __builtin_amdgcn_s_setprio(3);
+          else if (pr == 1) __builtin_amdgcn_s_setprio(2);
+          else if (pr == 2) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+        const int Sin = S;
+        PG_ST(18, 1);
+        PG_T0(ts0);
+        const int rc = scan(S, send < nextCk ? send : nextCk, send - 1);
+        PG_T1(16, ts0);
+        PG_ST(0, S - Sin + (rc ? 1 : 0));                   // (counted here: nothing but the loop's own state lives in scan())
+        PG_ST(9, resweep ? S - Sin + (rc ? 1 : 0) : 0);
+        if (S != Sin) drun = 0;                             // a clean stretch ends a series of dense runs
+        if (rc == 0) continue;
+        if (rc == 1) {                                      // candidates queued, the MFMA form goes on
+          PG_T0(tq0);
+          push_signs(S);
+          PG_T1(17, tq0);
+          ++S;
+          drun = 0;
+          continue;
+        }
+        // the signature is not selective here: a run of the dense form
+        const int drun0 = K().mmDirectRun;
+        if (!drun) drun = drun0;
+        dEnd = S + drun < send ? S + drun : send;
+        drun = drun * 2 < 8 * drun0 ? drun * 2 : 8 * drun0;  // back off while every probe is dense
+        PG_ST(3, 1);
+        PG_ST(4, dEnd - S);
       }
       if constexpr (MODE == PG_MODE_KNN) {
         if (!failed || resweep) break;
-        // phase 1: the rows that lost their cap see the first `sredo` super-tiles of the (rotated) sweep again; the others are frozen
+        // phase 1: the rows that lost their cap see super-tiles [0, sredo) again; the others are frozen
         resweep = 1;
-        loose = 1;
-        lck = kNoCk;
+        nextCk = kNoCk;
         set_all_bounds((lane < nr && ((failed >> lane) & 1ull)) ? (thrv >> 24) + 1u : 0u);
-        lend = sredo;
+        send = sredo;
       } else {
         break;
       }
