@@ -78,23 +78,24 @@ int pg_ngroups(int l) { return l <= 0 ? 1 : (l + 31) / 32; }
 int pg_nchunks(int l, int bits) { return (pg_ngroups(l) * bits + 3) / 4; }
 int64_t pg_planes_bytes(int64_t n, int l, int bits) { return ((int64_t)pg_nchunks(l, bits) * 16 + PG_AUX_BYTES) * pg_npad(n); }
 // launch-private device state of an all-pairs call, sized by the row count:
-//   [0, 64)      pass counters of the engine's persistent waves (words 0, 4, 8, 12: a call's main launch, its column
-//                pieces, its gated 32-row alternative, its repair launch)
-//   [64, 576)    one flag word per row block of a launch in column pieces (knn_launch)     - zeroed with the counters
+//   [0, 64)      pass counters of the engine's persistent waves (words 0 and 8: a call's main launch and its gated 32-row
+//                alternative) and, word 1, the number of evicted rows                        - zeroed by the call
+//   [64, 576)    (reserved; zeroed with the counters)
 //   [576, 640)   the probe's decision words (gates)
 //   [640, ...)   the probe's counts (8 * PG_PROBE_ROWS * PG_PROBE_WAVES bytes)
 //   from PG_WS_PARTIAL on, launches of more than PG_SPLIT_MIN_ROWS rows: the lists of the column pieces - at most
-//                PG_SPLIT_MAX_ROWS rows x 8 pieces (or half of them x 16) x PG_MM_KL keys
+//                PG_SPLIT_MAX_ROWS rows x 8 pieces (or half of them x 16) x PG_MM_KL keys; then the evicted rows (below)
 #define PG_WS_FLAGS 64
 #define PG_WS_GATES 576
 #define PG_WS_COUNTS 640
 #define PG_WS_PARTIAL (PG_WS_COUNTS + 8 * 64 * 128)
 #define PG_SPLIT_MAX_ROWS 8192       // 128 row blocks of 64
 #define PG_SPLIT_MIN_ROWS 65536     // (launches up to here never split)
-static_assert(PG_WS_GATES - PG_WS_FLAGS >= 4 * (PG_SPLIT_MAX_ROWS / (2 * PG_MM_RB)), "one flag word per 64-row block");
-int64_t pg_workspace_bytes(int64_t nrows) {
-  return PG_WS_PARTIAL + (nrows > PG_SPLIT_MIN_ROWS ? (int64_t)PG_SPLIT_MAX_ROWS * 8 * PG_MM_KL * 4 : 0);
-}
+#define PG_WS_PARTIAL_BYTES ((int64_t)PG_SPLIT_MAX_ROWS * 8 * PG_MM_KL * 4)
+// ... and behind that (every launch) one word per row: the rows a kNN launch of the MFMA engine evicts (NsqParams::mmEvict;
+// their number: word 1 of the counter line)
+static int64_t ws_evict_offset(int64_t nrows) { return PG_WS_PARTIAL + (nrows > PG_SPLIT_MIN_ROWS ? PG_WS_PARTIAL_BYTES : 0); }
+int64_t pg_workspace_bytes(int64_t nrows) { return ws_evict_offset(nrows) + 4 * (nrows > 0 ? nrows : 0) + 64; }
 
 }  // extern "C"
 
@@ -428,10 +429,10 @@ __global__ __launch_bounds__(1024) void pg_decide_kernel(const u32 *counts, int 
 // lanes per row, lane b holds the head of list b: k + 1 rounds of "smallest head wins and advances" (keys are
 // distance << 24 | column: unique, except 0xFFFFFFFF = no entry).  Four rows per wave.
 // A piece's list is exact below the optimistic cap only (NsqParams::mmPieces): a row whose merged (k+1)-th distance is
-// not below `cap` flags its block of `blockRows` rows for the repair launch.
+// not below `cap` joins the evicted rows (NsqParams::mmEvict: pg_knn_rows_kernel finishes them).
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_knn_merge_kernel(const u32 *partial, long long nrows, int pieces, int k, int *idx,
-                                                                     unsigned char *dist, u32 cap, int blockRows, u32 *blockFlags,
-                                                                     const u32 *gate, u32 gateWant) {
+                                                                     unsigned char *dist, u32 cap, u32 *evictCount, u32 *evictRows,
+                                                                     long long rowAbs0, const u32 *gate, u32 gateWant) {
   __shared__ u32 keys[PG_WG_WAVES][4][16 * PG_MM_KL];
   if (gate && __builtin_nontemporal_load(gate) != gateWant) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, b = lane & 15;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_knn_merge_kernel(const u32 *
         idx[row * k + r - 1] = m == 0xFFFFFFFFu ? -1 : (int)(m & 0x00FFFFFFu);
         dist[row * k + r - 1] = (unsigned char)(m >> 24);
       }
-      if (r == k && (m >> 24) >= cap) blockFlags[row / blockRows] = 1u;   // (0xFFFFFFFF, no entry, reads 255)
+      if (r == k && (m >> 24) >= cap) evictRows[atomicAdd(evictCount, 1u)] = (u32)(rowAbs0 + row);   // (0xFFFFFFFF, no entry, reads 255)
     }
     if (mine && head == m && m != 0xFFFFFFFFu) {           // the winner (unique key) moves on in its list
       ++pos;
@@ -469,6 +470,9 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_knn_merge_kernel(const u32 *
 }
 
 typedef int (*probe_fn)(int, const ProbeParams &, hipStream_t);
+typedef int (*knn_rows_fn)(int, const KnnRowsParams &, int, hipStream_t);
+static const knn_rows_fn kKnnRows[8] = {pg_launch_knn_rows_g1, pg_launch_knn_rows_g2, pg_launch_knn_rows_g3, pg_launch_knn_rows_g4,
+                                        pg_launch_knn_rows_g5, pg_launch_knn_rows_g6, pg_launch_knn_rows_g7, pg_launch_knn_rows_g8};
 static const probe_fn kProbe[8] = {pg_launch_probe_g1, pg_launch_probe_g2, pg_launch_probe_g3, pg_launch_probe_g4,
                                    pg_launch_probe_g5, pg_launch_probe_g6, pg_launch_probe_g7, pg_launch_probe_g8};
 // PG_PROBE=0: no probe (the size rules alone); PG_GATE_FORCE=<bits>: the decision is forced (tests): bit 0 gate[0], bit 1 gate[1]
@@ -1042,7 +1046,8 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     const int ng = pg_ngroups(l);
     const int occ1 = mm_occupancy(ng, shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN, bits);
     const int occ2 = shortList ? mm_occupancy(ng, PG_MODE_KNN_SHORT2, bits) : 0;
-    const bool canSplit = shortList && workspace && p.knnGuess > 0 && ncols >= 65536 && nrows > PG_SPLIT_MIN_ROWS &&
+    const bool evictOn = !(getenv("PG_MM_EVICT") && atoi(getenv("PG_MM_EVICT")) == 0);
+    const bool canSplit = shortList && workspace && evictOn && p.knnGuess > 0 && ncols >= 65536 && nrows > PG_SPLIT_MIN_ROWS &&
                           !getenv("PG_ROWS_PER_WAVE") && !(getenv("PG_MM_SPLIT") && atoi(getenv("PG_MM_SPLIT")) == 0);
     long long main1 = nrows, main2 = nrows;
     const double t1 = knn_plan_cost(nrows, ncols, PG_MM_RB, occ1, canSplit, &main1);
@@ -1055,8 +1060,23 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     plan_mm(mainRows, &p, &grid, rbm, occm, true);
     p.nrows = mainRows;
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
+    // rows that lose their optimistic cap are evicted from their passes and finished by pg_knn_rows_kernel behind the
+    // launch (NsqParams::mmEvict; PG_MM_EVICT=0: the second phase inside the pass, as before)
+    const bool evict = first == 1 && !floor_keys && !last_keys && p.knnGuess > 0 && evictOn;
+    if (evict) {
+      p.mmEvict = (u32 *)workspace + 1;                     // (word 1 of the counter line: zeroed by pass_counter)
+      p.mmEvictRows = (u32 *)((char *)workspace + ws_evict_offset(nrows));
+    }
+    auto finish_evicted = [&]() -> int {
+      if (!evict) return 0;
+      KnnRowsParams kr;
+      kr.rowPlanes = p.rowPlanes; kr.colPlanes = p.colPlanes; kr.rowNpad = p.rowNpad; kr.colNpad = p.colNpad; kr.ncols = p.ncols;
+      kr.count = p.mmEvict; kr.rows = p.mmEvictRows; kr.baseRow = row0; kr.k = k;
+      kr.knnIdx = idx_out; kr.knnDist = dist_out; kr.gate = p.gate; kr.gateWant = 0u;
+      const long long cap = (long long)(cu_count() > 0 ? cu_count() : 256) * 8;   // (one workgroup per row, the rows in turns)
+      return launched(kKnnRows[ng - 1](bits, kr, (int)(nrows < cap ? nrows : cap), (hipStream_t)stream), "pg_knn_rows_kernel");
+    };
     if (mainRows < nrows) {
-      NsqParams q;
       const long long rem = nrows - mainRows, nb = (rem + rbm - 1) / rbm;
       const long long simds = (long long)(cu_count() > 0 ? cu_count() : 256) * 4;
       int pieces = (int)(simds / nb);                       // (nb <= 128: at least 8; nb * pieces <= 1024 passes = the workspace's share)
@@ -1077,20 +1097,10 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
         grid = (int)(p.mmGridWaves / PG_WG_WAVES);
       }
       if (int rc = launched(kMm[ng - 1](modeM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn + column pieces)")) return rc;
-      q = p;
-      q.row0 = p.row0 + mainRows; q.nrows = rem;
-      u32 *flags = (u32 *)((char *)workspace + PG_WS_FLAGS);   // one word per row block (zeroed with the counters)
       pg_knn_merge_kernel<<<dim3((unsigned)((rem + 4 * PG_WG_WAVES - 1) / (4 * PG_WG_WAVES))), dim3(PG_WG_THREADS), 0, (hipStream_t)stream>>>(
-          p.mmPartial, rem, pieces, k, idx_out + mainRows * k, dist_out + mainRows * k, p.knnGuess, rbm, flags, p.gate, p.gateWant);
+          p.mmPartial, rem, pieces, k, idx_out + mainRows * k, dist_out + mainRows * k, p.knnGuess, p.mmEvict, p.mmEvictRows,
+          (long long)row0 + mainRows, p.gate, p.gateWant);
       if (int rc = launched((int)hipGetLastError(), "pg_knn_merge_kernel")) return rc;
-      // the repair launch: the same rows in plain passes, the blocks the merge did not flag skipped
-      NsqParams f = q;
-      f.mmPieces = 0; f.mmPieceFrom = 0; f.mmPartial = nullptr; f.mmBlockFlags = flags;
-      f.rowsPerWave = rbm; f.rowsPerPass = rbm; f.mmTailFrom = nb; f.mmTailRows = rbm;
-      f.mmPasses = nb; f.mmGridWaves = (nb + PG_WG_WAVES - 1) / PG_WG_WAVES * PG_WG_WAVES;
-      f.mmPassCounter = p.mmPassCounter + 12;
-      f.knnIdx = idx_out + mainRows * k; f.knnDist = dist_out + mainRows * k;
-      if (int rc = launched(kMm[ng - 1](modeM, bits, f, (int)(f.mmGridWaves / PG_WG_WAVES), (hipStream_t)stream), "pg_mm_kernel(knn, repair)")) return rc;
       p.nrows = nrows;                                      // (the gated 32-row alternative below covers all rows)
     }
     if (two && p.gate && !getenv("PG_MM_R")) {
@@ -1098,14 +1108,16 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
       NsqParams q = p;
       int qgrid = 0;
       q.mmPieces = 0; q.mmPieceFrom = 0; q.mmPartial = nullptr;
+      q.mmEvict = nullptr; q.mmEvictRows = nullptr;         // (one cluster: every row has its neighbours; the second phase if not)
       plan_mm(nrows, &q, &qgrid, PG_MM_RB, occ1, true);
       q.mmPassCounter = p.mmPassCounter + 8;
       q.gateWant = 2u;
       if (int rc = launched(kMm[pg_ngroups(l) - 1](PG_MODE_KNN_SHORT, bits, q, qgrid, (hipStream_t)stream), "pg_mm_kernel(knn, 32-row passes, gated)")) return rc;
     }
-    if (mainRows < nrows) return 0;                         // (the main launch and the pieces are out already)
-    return launched(kMm[pg_ngroups(l) - 1](two ? PG_MODE_KNN_SHORT2 : (shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN), bits, p, grid,
-                                           (hipStream_t)stream), "pg_mm_kernel(knn)");
+    if (mainRows < nrows) return finish_evicted();          // (the main launch and the pieces are out already)
+    if (int rc = launched(kMm[pg_ngroups(l) - 1](two ? PG_MODE_KNN_SHORT2 : (shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN), bits, p, grid,
+                                                 (hipStream_t)stream), "pg_mm_kernel(knn)")) return rc;
+    return finish_evicted();
   }
   return launch_valu(p);
 }

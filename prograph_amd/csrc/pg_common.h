@@ -296,13 +296,17 @@ struct NsqParams {
   // row' counted from the first row in pieces;
   // pg_knn_merge_kernel makes the rows' results of them.  (The rows one full round of waves cannot hold, pg_api.hip.)
   // A piece never gives up the optimistic cap (no checkpoints, no second phase): its list is exact for every column
-  // below the cap, so a merged list whose (k+1)-th distance ends below the cap is exact; the merge flags the row
-  // blocks where a row's does not (mmBlockFlags[block] = 1), and a third launch - the plain kernel over the same
-  // rows, passes whose flag is 0 skipped - sweeps those blocks again in full.
+  // below the cap, so a merged list whose (k+1)-th distance ends below the cap is exact; the merge hands the rows
+  // where it does not to pg_knn_rows_kernel (mmEvict below).
+  // pg_mm.h kNN: rows that lose their optimistic cap at a checkpoint are EVICTED when they are few in their pass (an open bound
+  // in a pass of 63 settled rows turns every remaining tile of the pass into dense-form work: 0.1 % of unrelated sequences among
+  // cfg3's took the launch from 1.7 to 28 ms): their index goes to mmEvictRows[atomicAdd(mmEvict, n) ...], their bound to 0,
+  // their results come from pg_knn_rows_kernel (pg_nsq.h) behind the launch.  Null: the second phase inside the pass, as before.
+  u32 *mmEvict;                     // the counter (zeroed with the pass counters)
+  u32 *mmEvictRows;
   int mmPieces;
   long long mmPieceFrom;            // passes from this index on are column pieces (the ones before: plain passes of rowsPerWave rows)
   u32 *mmPartial;                   // ... of the rows from mmPieceFrom * rowsPerWave on
-  const u32 *mmBlockFlags;          // != null: pass i runs only if mmBlockFlags[i] != 0
   int mmDenseL1, mmDenseL2, mmDirectRun;   // pg_mm.h: density rules of the filter hierarchy
   // data-driven choice between engines / paths WITHOUT a host round trip (pg_api.hip: probe): when `gate` is not
   // NULL the kernel runs only if *gate == gateWant (a device word the probe's decision kernel wrote on the same
@@ -351,6 +355,19 @@ struct DenseParams {
   int accumulate;   // 1: out += distance (sequences longer than one record are summed segment by segment)
 };
 
+// pg_knn_rows_kernel: exact kNN of single rows (the rows the MFMA engine evicted), one wave per row
+struct KnnRowsParams {
+  const uint4 *rowPlanes, *colPlanes;
+  long long rowNpad, colNpad, ncols;
+  const u32 *count, *rows;   // *count rows, rows[i] = row index (as in rowPlanes)
+  long long baseRow;         // output row of row index r: r - baseRow
+  int k;
+  int *knnIdx;
+  unsigned char *knnDist;
+  const u32 *gate;
+  u32 gateWant;
+};
+
 struct CompactParams {
   NsqParams e;
   int skipOverflow;   // 1: rows beyond their slot are left to pg_eps_fill_rows instead of being recomputed here
@@ -368,7 +385,8 @@ void pg_set_error(const char *msg);   // thread-local message behind pg_last_err
   int pg_launch_mm_g##G(int mode, int bits, const NsqParams &p, int grid, hipStream_t s); /* MFMA stage 1 (pg_mm.h) */ \
   int pg_launch_dense_g##G(int bits, const DenseParams &p, hipStream_t s);                    \
   int pg_launch_compact_g##G(int bits, const CompactParams &p, hipStream_t s);                \
-  int pg_launch_probe_g##G(int bits, const ProbeParams &p, hipStream_t s);
+  int pg_launch_probe_g##G(int bits, const ProbeParams &p, hipStream_t s);                    \
+  int pg_launch_knn_rows_g##G(int bits, const KnnRowsParams &p, int grid, hipStream_t s);
 PG_DECL_G(1) PG_DECL_G(2) PG_DECL_G(3) PG_DECL_G(4) PG_DECL_G(5) PG_DECL_G(6) PG_DECL_G(7) PG_DECL_G(8)
 int pg_launch_nsq_bag(const NsqParams &p, int grid, hipStream_t s);   // pg_lev.hip
 int pg_launch_nsq_bag_sym(const NsqParams &p, int grid, hipStream_t s);

@@ -56,6 +56,8 @@ typedef int pg_v16i __attribute__((ext_vector_type(16)));
 #define PG_MM_GROUP_ROWS 4    // folded form: rows per group of straight-line code (their folds: 20 SGPRs in flight)
 #define PG_MM_DIRECT_RUN 8   // super-tiles of dense form before the MFMA filter is probed again
 #define PG_MM_PRIO_STEPS 16  // R = 2: steps of the progress-driven issue priority along a sweep
+#define PG_MM_EVICT_MAX 48   // kNN: up to this many rows of a pass that lose their cap at a checkpoint are evicted (NsqParams::mmEvict); more (nearly the
+                             // whole pass: data without neighbours inside the cap, e.g. clusters smaller than k + 1): the second phase in the pass
 #ifndef PG_EXP_SAMETILE
 #define PG_EXP_SAMETILE 0   // experiment builds: 1 = every fragment load reads the same super-tile (L1 hits; wrong results)
 #endif
@@ -179,15 +181,6 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   // grid; persistent waves spread that round over all SIMDs, where its waves run faster (fewer per SIMD).
   for (long long pass = gw; pass < p.mmPasses;) {
     // the rows of the pass: rowsPerWave each, mmTailRows from pass mmTailFrom on
-    if constexpr (kPar) {
-      // (the repair launch behind a launch in column pieces: only the row blocks the merge flagged)
-      if (p.mmBlockFlags && __builtin_nontemporal_load(&p.mmBlockFlags[pass]) == 0u) {
-        u32 nx = 0;
-        if (lane == 0) nx = atomicAdd(p.mmPassCounter, 1u);
-        pass = p.mmGridWaves + (long long)(u32)__builtin_amdgcn_readfirstlane((int)nx);
-        continue;
-      }
-    }
     // (column pieces, kPar instances: passes from mmPieceFrom on; uniform passes of rowsPerWave rows)
     const int npieces = kPar && p.mmPieces > 1 && pass >= p.mmPieceFrom ? p.mmPieces : 1;
     const long long rpass = npieces > 1 ? p.mmPieceFrom + (pass - p.mmPieceFrom) / npieces : pass;
@@ -242,6 +235,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     };
     const u32 G0 = (MODE == PG_MODE_KNN && canFilter) ? p.knnGuess : 0u;
     u64 failed = 0;                                         // kNN: rows that lost their optimistic cap (bit = row)
+    u64 evicted = 0;                                        // kNN: rows handed to pg_knn_rows_kernel (NsqParams::mmEvict): bound 0, no results from here
     u32 resweep = 0;                                        // kNN: 1 in phase 1 (early super-tiles again for the failed rows)
     int sredo = 0;                                          // kNN: super-tiles [0, sredo) are swept again for them
     // list geometry: lanes / entries [lfirst, lfirst + k) are written out, entry thrLane is the row's threshold
@@ -328,7 +322,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // kNN: the bounds of ALL rows from the row-indexed state (after a flush that moved several thresholds at once):
     // min(threshold distance [+1 in phase 1], cap); 0 for rows past nr and, in phase 1, for the frozen rows
     auto republish_all = [&]() {
-      const bool live = lane < nr && (!resweep || ((failed >> lane) & 1ull));
+      const bool live = lane < nr && (!resweep || ((failed >> lane) & 1ull)) && !((evicted >> lane) & 1ull);
       const u32 b = (thrv >> 24) + resweep;                 // open lists read 255
       set_all_bounds(live ? (b < capv ? b : capv) : 0u);
     };
@@ -791,7 +785,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     auto neg_bounds = [&]() -> u32 {
       if constexpr (kEps) return lane < nr ? 0u - p.hi1 : 0u;
       const u32 t = thrv >> 24;                             // open lists read 255
-      const bool live = lane < nr && (!resweep || ((failed >> lane) & 1ull));
+      const bool live = lane < nr && (!resweep || ((failed >> lane) & 1ull)) && !((evicted >> lane) & 1ull);
       return live ? 0u - ((t < capv ? t : capv) + resweep) : 0u;
     };
     auto load_rec = [&](uint4 (&dst)[Q], long long col) {
@@ -950,12 +944,22 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
         const int sw2 = (nst + 7) >> 3;
         const bool at2 = snext >= sw2;
         nextCk = at2 ? kNoCk : sw2;
-        const bool mine = lane < nr && !((failed >> lane) & 1ull);
+        const bool mine = lane < nr && !((failed >> lane) & 1ull) && !((evicted >> lane) & 1ull);
         u32 dref = thrv >> 24;                             // open lists read 255
         if (!at2) dref = mine ? lstbuf[wv][lane < RB ? lane : 0][lfirst] >> 24 : 0u;
         const bool late = mine && dref >= G0;
         const u64 now = __builtin_amdgcn_ballot_w64(late);
-        if (now) {
+        const auto &ke = K();
+        if (now && ke.mmEvict && __popcll(now) <= PG_MM_EVICT_MAX) {
+          // a few rows of the pass: out with them (an open bound among settled rows costs the whole pass its filter)
+          u32 base = 0;
+          if (lane == 0) base = atomicAdd(ke.mmEvict, (u32)__popcll(now));
+          base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+          if (late) ke.mmEvictRows[base + mask_rank(now)] = (u32)(ke.row0 + pr0 + lane);
+          evicted |= now;
+          const u32 b = thrv >> 24;
+          set_all_bounds((lane < nr && !((evicted >> lane) & 1ull)) ? (b < capv ? b : capv) : 0u);
+        } else if (now) {
           failed |= now;
           sredo = snext;
           if (late) capv = 255u;
@@ -1116,11 +1120,13 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
           const int rr = e / kk, j = e - rr * kk;
           const u32 key = lstbuf[wv][rr][KL - kk + j];
           const long long o = pr0 * (long long)kk + e;
+          if ((evicted >> rr) & 1ull) continue;             // (pg_knn_rows_kernel writes these)
           kr.knnIdx[o] = (key == 0xFFFFFFFFu) ? -1 : (int)(key & 0x00FFFFFFu);
           kr.knnDist[o] = (unsigned char)(key >> 24);
         }
       } else {
         for (int rr = 0; rr < nr; ++rr) {
+          if ((evicted >> rr) & 1ull) continue;             // (pg_knn_rows_kernel writes these)
           const u32 key = lstbuf[wv][rr][lane];
           if (lane >= kr.knnFirst && lane < kr.knnFirst + kr.k) {
             const long long o = (pr0 + rr) * (long long)kr.k + (lane - kr.knnFirst);

@@ -631,6 +631,100 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_dense_kernel(const DensePara
 }
 
 // ---------------------------------------------------------------------------------------
+// Exact kNN of single rows: the rows the MFMA engine evicted from their passes (NsqParams::mmEvict) - rows without k + 1
+// columns inside the optimistic cap, whose bound cannot be tight - and the rows of column pieces whose merged list the
+// cap may have cut short (pg_knn_merge_kernel).  A WORKGROUP takes eight rows at a time: its four waves take every fourth
+// tile of 128 columns (lane = 2 columns; one load of the column records serves the eight rows - a row alone streams the
+// whole operand, 9.6 MB at cfg3: 10 000 evicted rows were 3.7 ms of L2 traffic), every distance, the k + 1 smallest
+// (distance, column) keys of a row across the lanes of each wave (lane j = j-th smallest: insertion = one DPP shift); the
+// waves then merge the four lists of two rows each through LDS and write ranks 1..k (prograph/prograph.py:761-763).
+// ---------------------------------------------------------------------------------------
+template <int G, int B>
+__global__ __launch_bounds__(PG_WG_THREADS) void pg_knn_rows_kernel(const KnnRowsParams p) {
+  constexpr int Q = Rec<G, B>::Q;
+  constexpr int CR = 2;                                    // columns per lane and turn
+  constexpr int RW = 8;                                    // rows per workgroup and turn
+  __shared__ uint4 rowrec[RW][Q];
+  __shared__ u32 lists[PG_WG_WAVES][RW][64];
+  if (p.gate && __builtin_nontemporal_load(p.gate) != p.gateWant) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long count = (long long)__builtin_nontemporal_load(p.count);
+  const int kk = p.k;
+  for (long long g0 = (long long)blockIdx.x * RW; g0 < count; g0 += (long long)gridDim.x * RW) {
+    const int nrw = (int)(count - g0 < RW ? count - g0 : RW);
+    __syncthreads();                                       // (the previous rows' lists and records are done with)
+    for (int e = threadIdx.x; e < RW * Q; e += PG_WG_THREADS) {
+      const int rr = e / Q, q = e - rr * Q;
+      rowrec[rr][q] = p.rowPlanes[(long long)q * p.rowNpad + (long long)p.rows[g0 + (rr < nrw ? rr : 0)]];
+    }
+    __syncthreads();
+    const uint4 *rrec = &rowrec[0][0] + opaque_zero();     // broadcast reads, kept "divergent"
+    u32 lst[RW], thr[RW];                                  // row rr: lane j = its j-th smallest key so far; thr = lane k's
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) { lst[rr] = 0xFFFFFFFFu; thr[rr] = 0xFFFFFFFFu; }
+    const long long ntiles = (p.ncols + 64 * CR - 1) / (64 * CR);
+    for (long long t = wv; t < ntiles; t += PG_WG_WAVES) {
+      uint4 c[CR][Q];
+#pragma unroll
+      for (int b = 0; b < CR; ++b) {
+        const long long col = t * (64 * CR) + b * 64 + lane;   // (the plane buffer is padded to 256 sequences: in bounds)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) c[b][q] = p.colPlanes[(long long)q * p.colNpad + col];
+      }
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        if (rr >= nrw) break;
+        uint4 r[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) r[q] = rrec[rr * Q + q];
+#pragma unroll
+        for (int b = 0; b < CR; ++b) {                      // (ascending columns: slices, then lanes)
+          const long long col = t * (64 * CR) + b * 64 + lane;
+          const u32 key = col < p.ncols ? (mismatch<G, B>(r, c[b]) << 24) | (u32)col : 0xFFFFFFFFu;
+          u64 m = __builtin_amdgcn_ballot_w64(key < thr[rr]);
+          while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const u32 x = (u32)__builtin_amdgcn_readlane((int)key, j);
+            if (x < thr[rr]) {
+              const u32 prev = wave_shr1(lst[rr], 0u);
+              lst[rr] = (lst[rr] <= x) ? lst[rr] : (prev > x ? prev : x);
+              thr[rr] = (u32)__builtin_amdgcn_readlane((int)lst[rr], kk);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) lists[wv][rr][lane] = lst[rr];
+    __syncthreads();
+    for (int rr = wv; rr < nrw; rr += PG_WG_WAVES) {       // wave w merges the four lists of rows w and w + 4
+      u32 l = lists[0][rr][lane];
+      u32 t = (u32)__builtin_amdgcn_readlane((int)l, kk);
+      for (int w = 1; w < PG_WG_WAVES; ++w) {
+        const u32 other = lists[w][rr][lane];
+        u64 m = __builtin_amdgcn_ballot_w64(other < t && lane <= kk);
+        while (m) {
+          const int j = __builtin_ctzll(m);
+          m &= m - 1;
+          const u32 x = (u32)__builtin_amdgcn_readlane((int)other, j);
+          if (x < t) {
+            const u32 prev = wave_shr1(l, 0u);
+            l = (l <= x) ? l : (prev > x ? prev : x);
+            t = (u32)__builtin_amdgcn_readlane((int)l, kk);
+          }
+        }
+      }
+      if (lane >= 1 && lane <= kk) {
+        const long long o = ((long long)p.rows[g0 + rr] - p.baseRow) * (long long)kk + (lane - 1);
+        p.knnIdx[o] = l == 0xFFFFFFFFu ? -1 : (int)(l & 0x00FFFFFFu);
+        p.knnDist[o] = (unsigned char)(l >> 24);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Data probe in front of a large all-pairs launch: exact distances of a few sample rows against all columns, counted
 // (see ProbeParams).  Grid: nsample * wavesPerRow waves; wave w of a sample row takes every wavesPerRow-th tile of 64
 // columns.  ~1e-3 of the launch's pair count.

@@ -104,6 +104,17 @@ static int launch_dense(const DenseParams &p, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+template <int B>
+static int launch_knn_rows(const KnnRowsParams &p, int grid, hipStream_t s) {
+  if constexpr (!Cols<B>::kBuilt) return (int)hipErrorInvalidValue;
+  pg_knn_rows_kernel<PG_G, B><<<dim3(grid), dim3(PG_WG_THREADS), 0, s>>>(p);
+  return (int)hipGetLastError();
+}
+
+int PG_CAT(pg_launch_knn_rows_g, PG_G)(int bits, const KnnRowsParams &p, int grid, hipStream_t s) {
+  return bits == 5 ? launch_knn_rows<5>(p, grid, s) : launch_knn_rows<8>(p, grid, s);
+}
+
 int PG_CAT(pg_launch_dense_g, PG_G)(int bits, const DenseParams &p, hipStream_t s) {
   return bits == 5 ? launch_dense<5>(p, s) : launch_dense<8>(p, s);
 }
