@@ -938,10 +938,21 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
     // drain: one copy of flush).  No checkpoints without a cap and in phase 1.
     constexpr int kNoCk = 0x7FFFFFFF;
     // (a column piece keeps the cap to its end: what the cap hides from it, the merge detects - NsqParams::mmPieces)
-    int nextCk = (MODE == PG_MODE_KNN && G0 && npieces == 1) ? ((nst + 31) >> 5) : kNoCk;
+    // With eviction (NsqParams::mmEvict) a row is judged ONCE, and not before the sweep has passed the pass's own rows
+    // (a self graph: column index = row index): where similar sequences sit together (a file sorted by family or by name)
+    // a row meets its neighbours around its own position, and judged at 1/32 or 1/8 of the sweep a whole pass would look
+    // unclustered (cfg3's sequences in lexicographic order: 17.9 ms).  Waiting costs nothing - a capped row has a bound of
+    // G0, no candidates among unrelated sequences - and a row that fails is evicted, not swept again.  A pass whose own
+    // rows lie at the end of the columns is judged at the end of the sweep.
+    const bool judgeOnce = MODE == PG_MODE_KNN && p.mmEvict != nullptr;
+    int sw2 = (nst + 7) >> 3;
+    if (judgeOnce) {
+      const long long own = (K().row0 + pr0) / PG_MM_ST + 8;   // (eight super-tiles past: neighbours on both sides)
+      if (own > sw2) sw2 = own < nst ? (int)own : nst;
+    }
+    int nextCk = (MODE == PG_MODE_KNN && G0 && npieces == 1) ? (judgeOnce ? sw2 : ((nst + 31) >> 5)) : kNoCk;
     auto checkpoint = [&](int snext) {                      // the sweep has reached super-tile snext >= nextCk; queue empty
       if constexpr (MODE == PG_MODE_KNN) {
-        const int sw2 = (nst + 7) >> 3;
         const bool at2 = snext >= sw2;
         nextCk = at2 ? kNoCk : sw2;
         const bool mine = lane < nr && !((failed >> lane) & 1ull) && !((evicted >> lane) & 1ull);
