@@ -16,7 +16,8 @@
  *     pg_knn_hamming[_round]) take a caller-owned `workspace` of pg_workspace_bytes(nrows)
  *     bytes: launch-private device state (the pass counters of the engine's persistent waves,
  *     the data probe's counts and decision words, and - kNN calls of more than 65 536 rows,
- *     5.2 MB - the partial neighbour lists of rows swept in column pieces),
+ *     5.2 MB - the partial neighbour lists of rows swept in column pieces; one word per row for
+ *     the rows a kNN launch finishes separately),
  *     initialised by the call on `stream`; ONE workspace per launch in flight - a workspace
  *     may be reused once the launch that got it has completed, or by later launches on the
  *     same stream;

@@ -411,6 +411,40 @@ def test_rows_beyond_a_full_round_in_column_pieces(nat, case, monkeypatch):
 
 
 @one_engine
+@pytest.mark.parametrize("case", ["outliers", "sorted", "shuffled", "outliers, byte alphabet, k=40"])
+def test_rows_that_lose_their_cap_are_evicted(nat, case, monkeypatch):
+    """Rows without k + 1 columns inside the optimistic cap (unrelated sequences among clustered ones; members of a family
+    that a sorted file puts far from the others) leave their pass and are finished by pg_knn_rows_kernel; a row is judged
+    only after the sweep has passed its own position.  Every entry against the oracle, with and without eviction."""
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    N, k, bits = 60_000, 16, 5
+    tok = synth.clustered_tokens(N, 64, members=120)
+    rng = np.random.RandomState(11)
+    if case.startswith("outliers"):
+        rows = rng.choice(N, N // 50, replace=False)
+        tok[rows] = rng.randint(1, 21, size=(len(rows), 64)).astype(np.uint8)
+        tok[rows[:40]] = tok[rows[40:80]]                      # ... some of them in pairs: a near column, but not k + 1
+        if "byte" in case:
+            k, bits = 40, 8
+    elif case == "sorted":
+        tok = np.ascontiguousarray(tok[np.lexsort(tok.T[::-1])])
+    else:
+        tok = np.ascontiguousarray(tok[rng.permutation(N)])
+    p = nat.pack(torch.from_numpy(tok), bits=bits)
+    monkeypatch.setenv("PG_ENGINE", "mfma")
+    ridx, rd = C.knn(tok, k, fast=True)
+    for evict in ("1", "0"):
+        monkeypatch.setenv("PG_MM_EVICT", evict)
+        kidx, kd = nat.knn_graph(p, p, k)
+        torch.cuda.synchronize()
+        assert np.array_equal(kidx.cpu().numpy(), ridx) and np.array_equal(kd.cpu().numpy(), rd), (case, evict)
+    monkeypatch.delenv("PG_MM_EVICT")
+    kidx, kd = nat.knn_graph(p, p, k, row0=20_000, nrows=30_000)   # a window of the rows: evicted rows land in their place
+    assert np.array_equal(kidx.cpu().numpy(), ridx[20_000:50_000]) and np.array_equal(kd.cpu().numpy(), rd[20_000:50_000])
+
+
+@one_engine
 def test_full_windows_on_dense_data_and_on_the_sharded_slice(nat):
     """Whole 4 096-row windows against the oracle where a full matrix is out of reach on the host: (i) cfg3's shape on
     DENSE data (one cluster: the folded / exact forms of the engine), (ii) rank 3's block of BASELINE.json configs[3]
