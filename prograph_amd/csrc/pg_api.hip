@@ -432,9 +432,9 @@ __global__ __launch_bounds__(1024) void pg_decide_kernel(const u32 *counts, int 
 // not below `cap` joins the evicted rows (NsqParams::mmEvict: pg_knn_rows_kernel finishes them).
 __global__ __launch_bounds__(PG_WG_THREADS) void pg_knn_merge_kernel(const u32 *partial, long long nrows, int pieces, int k, int *idx,
                                                                      unsigned char *dist, u32 cap, u32 *evictCount, u32 *evictRows,
-                                                                     long long rowAbs0, const u32 *gate, u32 gateWant) {
+                                                                     long long rowAbs0, const u32 *gate, u32 gateMask) {
   __shared__ u32 keys[PG_WG_WAVES][4][16 * PG_MM_KL];
-  if (gate && __builtin_nontemporal_load(gate) != gateWant) return;
+  if (gate && !((gateMask >> __builtin_nontemporal_load(gate)) & 1u)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, b = lane & 15;
   const long long row0 = ((long long)blockIdx.x * PG_WG_WAVES + wv) * 4;
   if (row0 >= nrows) return;                               // (whole wave; no workgroup barrier below)
@@ -841,11 +841,11 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
     if (int rc = run_probe(p, l, bits, 0u, p.lo, p.span, 1u, workspace, (hipStream_t)stream, &gate)) return rc;
     NsqParams r = p;
     r.countsLo = nullptr;
-    r.gate = gate + 1; r.gateWant = 1u;
+    r.gate = gate + 1; r.gateMask = 1u << 1;
     int rgrid = 0;
     if (int rc = plan_rows(n, &r, &rgrid, nsq_occupancy(pg_ngroups(l), PG_MODE_EPS, bits), 16.0 * pg_nchunks(l, bits))) return rc;
     if (int rc = launched(kNsq[pg_ngroups(l) - 1](PG_MODE_EPS, bits, r, rgrid, (hipStream_t)stream), "pg_nsq_kernel(eps, gated)")) return rc;
-    p.gate = gate + 1; p.gateWant = 0u;
+    p.gate = gate + 1; p.gateMask = 1u << 0;
   }
   // Rows near the top sweep almost everything, rows near the bottom almost nothing; workgroups are
   // dispatched in row order, i.e. longest first, which balances by itself once there are a few
@@ -1025,9 +1025,9 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
       if (int rc = run_probe(p, l, bits, p.knnGuess, 1u, 0u, (u32)(first + k), workspace, (hipStream_t)stream, &gate)) return rc;
       NsqParams v = p;
       v.knnGuess = guessValu;
-      v.gate = gate; v.gateWant = 1u;
+      v.gate = gate; v.gateMask = 1u << 1;
       if (int rc = launch_valu(v)) return rc;
-      p.gate = gate; p.gateWant = 0u;
+      p.gate = gate; p.gateMask = (1u << 0) | (1u << 2);   // (2 = one cluster: the 32-row alternative below takes it over where it exists)
     }
     // short lists (the usual k): the instance that inserts a whole batch of candidates at once (pg_mm.h, KL).
     // PG_MM_SHORT=0 keeps the 64-lane lists (A/B runs)
@@ -1057,6 +1057,10 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
     const int rbm = two ? 2 * PG_MM_RB : PG_MM_RB, occm = two ? occ2 : occ1;
     const int modeM = two ? PG_MODE_KNN_SHORT2 : (shortList ? PG_MODE_KNN_SHORT : PG_MODE_KNN);
     const long long mainRows = two ? main2 : main1;
+    // the probe's "one cluster" (gate value 2) goes to the 32-row alternative where one is launched (below); elsewhere
+    // the main launch takes it as well
+    const bool alt32 = two && p.gate && !getenv("PG_MM_R");
+    if (p.gate) p.gateMask = alt32 ? (1u << 0) : ((1u << 0) | (1u << 2));
     plan_mm(mainRows, &p, &grid, rbm, occm, true);
     p.nrows = mainRows;
     if (int rc = pass_counter(&p, workspace, (hipStream_t)stream)) return rc;
@@ -1072,7 +1076,7 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
       KnnRowsParams kr;
       kr.rowPlanes = p.rowPlanes; kr.colPlanes = p.colPlanes; kr.rowNpad = p.rowNpad; kr.colNpad = p.colNpad; kr.ncols = p.ncols;
       kr.count = p.mmEvict; kr.rows = p.mmEvictRows; kr.baseRow = row0; kr.k = k;
-      kr.knnIdx = idx_out; kr.knnDist = dist_out; kr.gate = p.gate; kr.gateWant = 0u;
+      kr.knnIdx = idx_out; kr.knnDist = dist_out; kr.gate = p.gate; kr.gateMask = p.gateMask;
       const long long cap = (long long)(cu_count() > 0 ? cu_count() : 256) * 8;   // (one workgroup per row, the rows in turns)
       return launched(kKnnRows[ng - 1](bits, kr, (int)(nrows < cap ? nrows : cap), (hipStream_t)stream), "pg_knn_rows_kernel");
     };
@@ -1099,11 +1103,11 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
       if (int rc = launched(kMm[ng - 1](modeM, bits, p, grid, (hipStream_t)stream), "pg_mm_kernel(knn + column pieces)")) return rc;
       pg_knn_merge_kernel<<<dim3((unsigned)((rem + 4 * PG_WG_WAVES - 1) / (4 * PG_WG_WAVES))), dim3(PG_WG_THREADS), 0, (hipStream_t)stream>>>(
           p.mmPartial, rem, pieces, k, idx_out + mainRows * k, dist_out + mainRows * k, p.knnGuess, p.mmEvict, p.mmEvictRows,
-          (long long)row0 + mainRows, p.gate, p.gateWant);
+          (long long)row0 + mainRows, p.gate, p.gateMask);
       if (int rc = launched((int)hipGetLastError(), "pg_knn_merge_kernel")) return rc;
       p.nrows = nrows;                                      // (the gated 32-row alternative below covers all rows)
     }
-    if (two && p.gate && !getenv("PG_MM_R")) {
+    if (alt32) {
       // the probe may say "one cluster" (gate 2): the same engine with 32-row passes, launched as a third alternative
       NsqParams q = p;
       int qgrid = 0;
@@ -1111,7 +1115,7 @@ static int knn_launch(const void *row_planes, int64_t row_npad, int64_t row0, in
       q.mmEvict = nullptr; q.mmEvictRows = nullptr;         // (one cluster: every row has its neighbours; the second phase if not)
       plan_mm(nrows, &q, &qgrid, PG_MM_RB, occ1, true);
       q.mmPassCounter = p.mmPassCounter + 8;
-      q.gateWant = 2u;
+      q.gateMask = 1u << 2;
       if (int rc = launched(kMm[pg_ngroups(l) - 1](PG_MODE_KNN_SHORT, bits, q, qgrid, (hipStream_t)stream), "pg_mm_kernel(knn, 32-row passes, gated)")) return rc;
     }
     if (mainRows < nrows) return finish_evicted();          // (the main launch and the pieces are out already)

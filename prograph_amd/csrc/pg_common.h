@@ -309,10 +309,10 @@ struct NsqParams {
   u32 *mmPartial;                   // ... of the rows from mmPieceFrom * rowsPerWave on
   int mmDenseL1, mmDenseL2, mmDirectRun;   // pg_mm.h: density rules of the filter hierarchy
   // data-driven choice between engines / paths WITHOUT a host round trip (pg_api.hip: probe): when `gate` is not
-  // NULL the kernel runs only if *gate == gateWant (a device word the probe's decision kernel wrote on the same
+  // NULL the kernel runs only if bit *gate of gateMask is set (a device word the probe's decision kernel wrote on the same
   // stream); the alternatives are all launched, all but one leave at once
   const u32 *gate;
-  u32 gateWant;
+  u32 gateMask;
   int filter;   // 1 = plane-0 lower-bound filter allowed (adaptive per tile), 0 = always direct
   u32 knnGuess; // kNN: optimistic cap on the stage-1 bound until a row's list is full (0 = off), see pg_nsq.h
   // eps
@@ -365,7 +365,7 @@ struct KnnRowsParams {
   int *knnIdx;
   unsigned char *knnDist;
   const u32 *gate;
-  u32 gateWant;
+  u32 gateMask;
 };
 
 struct CompactParams {

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
   if (gw >= p.mmPasses) return;   // whole wave leaves; no workgroup barrier is used below
-  if (p.gate && __builtin_nontemporal_load(p.gate) != p.gateWant) return;   // the probe chose another engine / path
+  if (p.gate && !((p.gateMask >> __builtin_nontemporal_load(p.gate)) & 1u)) return;   // the probe chose another engine / path
   const uint4 *__restrict__ colp = p.colPlanes;
   const pg_v4i *__restrict__ colsig = reinterpret_cast<const pg_v4i *>(p.colSig);
   const u32 ncols = (u32)p.ncols;

@@ -53,7 +53,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == PG_MODE_KNN ? (C == 2 ? (M::Q <= 3 ? 
   const long long gw = (long long)blockIdx.x * PG_WG_WAVES + wv;
   const long long wr0 = gw * p.rowsPerWave;
   if (wr0 >= p.nrows) return;   // whole wave leaves; no workgroup barrier is used below
-  if (p.gate && __builtin_nontemporal_load(p.gate) != p.gateWant) return;   // the probe chose another engine / path
+  if (p.gate && !((p.gateMask >> __builtin_nontemporal_load(p.gate)) & 1u)) return;   // the probe chose another engine / path
   const long long wr1 = (wr0 + p.rowsPerWave < p.nrows) ? wr0 + p.rowsPerWave : p.nrows;
   const int ntiles = (int)((p.ncols + 64 * C - 1) / (64 * C));   // ncols < 2^31
   const uint4 *__restrict__ colp = p.colPlanes;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(PG_WG_THREADS) void pg_knn_rows_kernel(const KnnRow
   constexpr int RW = 8;                                    // rows per workgroup and turn
   __shared__ uint4 rowrec[RW][Q];
   __shared__ u32 lists[PG_WG_WAVES][RW][64];
-  if (p.gate && __builtin_nontemporal_load(p.gate) != p.gateWant) return;
+  if (p.gate && !((p.gateMask >> __builtin_nontemporal_load(p.gate)) & 1u)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long count = (long long)__builtin_nontemporal_load(p.count);
   const int kk = p.k;

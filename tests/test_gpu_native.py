@@ -411,6 +411,32 @@ def test_rows_beyond_a_full_round_in_column_pieces(nat, case, monkeypatch):
 
 
 @one_engine
+def test_every_probe_outcome_has_a_launch_that_takes_it(nat):
+    """One-cluster data below the row count of the 64-row instance: the probe says "one cluster" (gate value 2), for which
+    only launches with 64-row passes carry a separate alternative - the main launch must take it itself (it did not: every
+    launch of the call returned at its gate and the output was never written; tools/stress.py big found it)."""
+    from oracle import c_oracle as C
+    from prograph_amd import synth
+    N, k = 80_000, 16
+    tok = synth.clustered_tokens(N, 64, members=N)             # one cluster
+    p = nat.pack(torch.from_numpy(tok), bits=5)
+    kidx = torch.full((N, k), -7, dtype=torch.int32, device=p.buf.device)
+    kd = torch.full((N, k), 201, dtype=torch.uint8, device=p.buf.device)
+    nat.knn_graph(p, p, k, out=(kidx, kd))
+    torch.cuda.synchronize()
+    assert int((kidx == -7).sum()) == 0
+    ridx, rd = C.knn(tok, k, row0=40_000, nrows=2048, fast=True)
+    assert np.array_equal(kidx[40_000:42_048].cpu().numpy(), ridx) and np.array_equal(kd[40_000:42_048].cpu().numpy(), rd)
+    # short sequences of a byte alphabet: everything within the cap, k = 1, a window of the rows
+    rng = np.random.RandomState(4)
+    tok = rng.randint(0, 201, size=(135_000, 4)).astype(np.uint8)
+    p = nat.pack(torch.from_numpy(tok), bits=8)
+    kidx, kd = nat.knn_graph(p, p, 1, row0=26_176, nrows=97_713)
+    ridx, rd = C.knn(tok, 1, row0=26_176, nrows=97_713, fast=True)
+    assert np.array_equal(kidx.cpu().numpy(), ridx) and np.array_equal(kd.cpu().numpy(), rd)
+
+
+@one_engine
 @pytest.mark.parametrize("case", ["outliers", "sorted", "shuffled", "outliers, byte alphabet, k=40"])
 def test_rows_that_lose_their_cap_are_evicted(nat, case, monkeypatch):
     """Rows without k + 1 columns inside the optimistic cap (unrelated sequences among clustered ones; members of a family
