@@ -16,7 +16,7 @@ for it in range(iters):
     N = int(rng.choice([40000, 68000, 100000, 135000, 139000])) if BIG else int(rng.choice([300, 1000, 2500, 6000, 12000, 20000]))
     amax = int(rng.choice([2, 4, 20, 31, 200]))
     L = int(rng.randint(4, 255 if amax <= 31 else 129))
-    ncl = max(1, N // int(rng.choice([8, 24, 100, 400, 3000])))
+    ncl = max(1, N // int(rng.choice([8, 24, 100, 400, 3000] + ([N] if BIG else []))))   # (big: sometimes ONE cluster - the probe's third outcome)
     base = rng.randint(0, amax + 1, size=(ncl, L))
     tok = base[rng.randint(0, ncl, size=N)].copy()
     nm = rng.randint(0, int(rng.choice([2, 4, 12])), size=N)
@@ -26,7 +26,8 @@ for it in range(iters):
     nloose = int(N * rng.choice([0, 0, 0.1, 0.5]))
     if nloose:
         tok[rng.choice(N, nloose, replace=False)] = rng.randint(0, amax + 1, size=(nloose, L))
-    tok = tok[rng.permutation(N)].astype(np.uint8) if rng.rand() < 0.5 else tok.astype(np.uint8)
+    order = rng.rand()
+    tok = tok[rng.permutation(N)].astype(np.uint8) if order < 0.4 else (np.ascontiguousarray(tok[np.lexsort(tok.T[::-1])]).astype(np.uint8) if order < 0.6 else tok.astype(np.uint8))
     bits = 5 if (amax <= 31 and (L > 128 or rng.rand() < 0.7)) else 8
     os.environ["PG_KNN_GUESS"] = str(rng.choice([0, 2, 5, 8, 8, 8, 20]))
     if BIG and rng.rand() < 0.6: os.environ.pop("PG_KNN_GUESS")
