@@ -120,7 +120,10 @@ __device__ __forceinline__ int pg_or16(const pg_v16i &d) {
 // R = 2 - two row operands, every fragment feeds two MFMAs - halves that traffic per pair.  Per-row state is lane
 // indexed, a wave has 64 lanes: R <= 2.  Short lists only (LDS).
 template <class M, int MODE, int KL = 64, int R = 1>
-__global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(M::Q <= 3 ? 4 : 1, 8))) void pg_mm_kernel(const NsqParams p) {
+// (records of four chunks - byte alphabets at L <= 64 - in the 32-row short-list kNN instance: held at three waves per SIMD,
+//  168 VGPRs; left alone it takes 173 since the eviction code: two waves, N = 200k 2.05 -> 2.5 ms)
+__global__ __launch_bounds__(PG_WG_THREADS) __attribute__((amdgpu_waves_per_eu(
+    M::Q <= 3 ? 4 : ((M::Q == 4 && MODE == PG_MODE_KNN && KL < 64 && R == 1) ? 3 : 1), 8))) void pg_mm_kernel(const NsqParams p) {
   constexpr int Q = M::Q;
   constexpr bool kPar = MODE == PG_MODE_KNN && KL < 64;    // lane-per-candidate insertion
   static_assert(KL == 64 || (KL % 4 == 0 && KL >= 8 && KL <= 32), "list entries: 64, or a multiple of 4 in 8..32");

@@ -9,8 +9,8 @@ def timeit(f, iters=9):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return float(np.median(ts))
-for N, L, members in ((200000, 64, 256), (100000, 128, 256), (50000, 32, 256), (200000, 64, 64)):
-    p = nat.pack(torch.from_numpy(synth.clustered_tokens(N, L, members=members)), bits=5)
+for N, L, members, bits in ((200000, 64, 256, 8), (100000, 64, 256, 8), (200000, 64, 256, 5), (270000, 64, 256, 5)):
+    p = nat.pack(torch.from_numpy(synth.clustered_tokens(N, L, members=members)), bits=bits)
     out = (torch.empty((N, 16), dtype=torch.int32, device=p.buf.device), torch.empty((N, 16), dtype=torch.uint8, device=p.buf.device))
     best = {}
     for rnd in range(3):
@@ -18,4 +18,4 @@ for N, L, members in ((200000, 64, 256), (100000, 128, 256), (50000, 32, 256), (
             os.environ.update(env); t = timeit(lambda: nat.knn_graph(p, p, 16, out=out))
             for k_ in env: os.environ.pop(k_)
             best[label] = min(best.get(label, 9e9), t)
-    print(f"N={N} L={L} members={members}: " + "  ".join(f"{k_} {v:.3f}" for k_, v in best.items()), flush=True)
+    print(f"N={N} L={L} bits={bits}: " + "  ".join(f"{k_} {v:.3f}" for k_, v in best.items()), flush=True)
