@@ -856,7 +856,7 @@ int pg_eps_slots_sym(const void *planes, int64_t npad, int64_t n, int l, int bit
     // the symmetric sweep's passes are not equal work (a pass sweeps the columns above its rows): about one and a half
     // rounds of passes balance best (tools/dbg/eps_plan.py: N = 50k 8 rows per pass 0.40 ms against 0.43 / 0.59 for 14 / 32;
     // N = 100k 16 rows 0.61 against 0.66 / 0.71 for 26 / 32; N = 200k 32 rows 1.12 against 1.62 for 16)
-    long long rs = (n + 6143) / 6144;
+    long long rs = (n + 6399) / 6400;                       // (tools/dbg/sym_rows.py: N = 50k 8 rows 0.375 ms, 10 rows 0.40; 40k: 8; 70k: 12)
     rs = (rs + 1) / 2 * 2;
     rs = rs < 8 ? 8 : (rs > PG_MM_RB ? PG_MM_RB : rs);
     // (records of up to three chunks - four waves per SIMD; longer ones, N = 100k L = 128: 0.75 against 0.67 with the old rule)
